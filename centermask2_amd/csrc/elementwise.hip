@@ -1,0 +1,315 @@
+// HBM-bound NHWC kernels of the backbone and the FCOS towers: stem conv on the raw NCHW image, ceil-mode max pool,
+// eSE (global average pool -> fc -> hsigmoid -> channel scale [+ identity]) and GroupNorm(32)+ReLU.
+// All of them move 16 bytes per lane (float4) with channels innermost, so a wave reads/writes whole 256 B-1 KiB runs.
+#include "cmk_common.hpp"
+
+namespace cmk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// stem_1 (vovnet.py:409): conv3x3 s2 p1 on (N,3,H,W) NCHW -> (N,Ho,Wo,Cout) NHWC, y = relu(acc*scale + shift).
+// 4 threads per output pixel, 16 output channels each (Cout = 64); 27 taps broadcast from LDS.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       float* __restrict__ y, int N, int H, int W, int Ho, int Wo, int Cout) {
+    extern __shared__ float sw[];  // [27][Cout] + scale[Cout] + shift[Cout]
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += 256) { sw[27 * Cout + i] = scale[i]; sw[28 * Cout + i] = shift[i]; }
+    __syncthreads();
+    const int groups = Cout >> 4;             // 16-channel groups per pixel
+    const int ppb = 256 / groups;             // pixels per block
+    const int g = threadIdx.x % groups;
+    const long pix = (long)blockIdx.x * ppb + threadIdx.x / groups;
+    const long total = (long)N * Ho * Wo;
+    if (pix >= total) return;
+    const int ow = (int)(pix % Wo);
+    const int oh = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long)Wo * Ho));
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const float* xn = x + (long)n * 3 * H * W;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+                float v = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xn[((long)ci * H + ih) * W + iw] : 0.f;
+                const float* wr = sw + ((kh * 3 + kw) * 3 + ci) * Cout + g * 16;  // tap-major [kh][kw][ci][co]
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+            }
+    float* yo = y + pix * Cout + g * 16;
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = g * 16 + j4 * 4 + j;
+            o[j] = fmaxf(acc[j4 * 4 + j] * sw[27 * Cout + c] + sw[28 * Cout + c], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(yo + j4 * 4) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MaxPool2d(3, 2, ceil_mode=True), no padding (vovnet.py:349-350).  One lane = one output pixel x 4 channels.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y,
+                                                      int y_cs, int y_co, int N, int H, int W, int Ho, int Wo, int C4) {
+    long total = (long)N * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = (int)(i % C4);
+        long p = i / C4;
+        int ow = (int)(p % Wo);
+        int oh = (int)((p / Wo) % Ho);
+        int n = (int)(p / ((long)Wo * Ho));
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int ih = oh * 2 + kh, iw = ow * 2 + kw;
+                if (ih < H && iw < W) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + ih) * W + iw) * x_cs + x_co + c4 * 4);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            }
+        *reinterpret_cast<f32x4*>(y + p * y_cs + y_co + c4 * 4) = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// eSE (vovnet.py:247-260).  Stage 1: per (image, pixel chunk) channel sums (deterministic: fixed order, no atomics).
+// Stage 2: mean -> fc (C x C mat-vec, one wave per output, wave64 shuffle reduction) -> relu6(v+3)/6.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ese_partial_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ ws,
+                                                         int HW, int C, int chunks) {
+    extern __shared__ float red[];  // [ppl][C]
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int G = C >> 2;
+    const int ppl = G >= 256 ? 1 : 256 / G;  // pixel lanes that share a channel group
+    const int per = cdiv(HW, chunks);
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    const float* xn = x + (long)n * HW * x_cs + x_co;
+    for (int gi = threadIdx.x; gi < G * ppl; gi += 256) {
+        int g = gi % G, pl = gi / G;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int p = p0 + pl; p < p1; p += ppl) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xn + (long)p * x_cs + g * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<f32x4*>(red + pl * C + g * 4) = s;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int pl = 0; pl < ppl; ++pl) s += red[pl * C + c];
+        ws[((long)n * chunks + chunk) * C + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void ese_fc_kernel(const float* __restrict__ ws, const float* __restrict__ fc_w,
+                                                    const float* __restrict__ fc_b, float* __restrict__ gate, int HW, int C,
+                                                    int chunks) {
+    extern __shared__ float mean[];  // [C]
+    const int n = blockIdx.y;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < chunks; ++k) s += ws[((long)n * chunks + k) * C + c];
+        mean[c] = s / (float)HW;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = blockIdx.x * 64 + wave; o < min(C, (int)(blockIdx.x + 1) * 64); o += 4) {
+        const float* wr = fc_w + (long)o * C;
+        float s = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+            s += wv.x * mean[c] + wv.y * mean[c + 1] + wv.z * mean[c + 2] + wv.w * mean[c + 3];
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            float v = s + fc_b[o] + 3.0f;
+            gate[(long)n * C + o] = fminf(fmaxf(v, 0.f), 6.f) / 6.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ese_scale_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ gate,
+                                                       const float* __restrict__ idn, int id_cs, int id_co, float* __restrict__ y,
+                                                       int y_cs, int y_co, int N, int HW, int C4) {
+    long total = (long)N * HW * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = (int)(i % C4);
+        long p = i / C4;
+        int n = (int)(p / HW);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + p * x_cs + x_co + c4 * 4);
+        f32x4 g = *reinterpret_cast<const f32x4*>(gate + (long)n * C4 * 4 + c4 * 4);
+        f32x4 o = {v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w};
+        if (idn) {
+            f32x4 d = *reinterpret_cast<const f32x4*>(idn + p * id_cs + id_co + c4 * 4);
+            o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+        }
+        *reinterpret_cast<f32x4*>(y + p * y_cs + y_co + c4 * 4) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm(32, C) + ReLU in place on a dense (N,HW,C) tensor (fcos.py:182-186).
+// Stage 1: per (image, pixel chunk) fp64 sum / sum-of-squares per group (fixed order).  Stage 2: normalise.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ ws, int HW, int C, int groups,
+                                                      int chunks) {
+    __shared__ double rs[256], rss[256];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int G = C >> 2;                    // float4 groups per pixel (<= 256 required)
+    const int ppl = 256 / G;
+    const int per = cdiv(HW, chunks);
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    const float* xn = x + (long)n * HW * C;
+    double s = 0.0, ss = 0.0;
+    const int g = threadIdx.x % G, pl = threadIdx.x / G;
+    if (pl < ppl) {
+        for (int p = p0 + pl; p < p1; p += ppl) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xn + (long)p * C + g * 4);
+            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+    }
+    rs[threadIdx.x] = s;
+    rss[threadIdx.x] = ss;
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        const int f4pg = (C / groups) >> 2;  // float4 groups per GN group
+        double a = 0.0, b = 0.0;
+        for (int l = 0; l < ppl; ++l)
+            for (int k = 0; k < f4pg; ++k) {
+                a += rs[l * G + threadIdx.x * f4pg + k];
+                b += rss[l * G + threadIdx.x * f4pg + k];
+            }
+        double* o = ws + (((long)n * groups + threadIdx.x) * chunks + chunk) * 2;
+        o[0] = a;
+        o[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const double* __restrict__ ws, int HW, int C, int groups, int chunks, float eps,
+                                                      int blocks_per_image) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int n = blockIdx.y;
+    if (threadIdx.x < groups) {
+        double a = 0.0, b = 0.0;
+        const double* w = ws + ((long)n * groups + threadIdx.x) * chunks * 2;
+        for (int k = 0; k < chunks; ++k) { a += w[2 * k]; b += w[2 * k + 1]; }
+        double cnt = (double)HW * (C / groups);
+        double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[threadIdx.x] = (float)mean;
+        s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    const int cpg = C / groups;
+    float* xn = x + (long)n * HW * C;
+    long total = (long)HW * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)blocks_per_image * 256) {
+        int c4 = (int)(i % C4);
+        int c = c4 * 4;
+        int grp = c / cpg;
+        float mean = s_mean[grp], rstd = s_rstd[grp];
+        f32x4 v = *reinterpret_cast<f32x4*>(xn + i * 4);
+        f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+        o.x = fmaxf((v.x - mean) * rstd * ga.x + be.x, 0.f);
+        o.y = fmaxf((v.y - mean) * rstd * ga.y + be.y, 0.f);
+        o.z = fmaxf((v.z - mean) * rstd * ga.z + be.z, 0.f);
+        o.w = fmaxf((v.w - mean) * rstd * ga.w + be.w, 0.f);
+        *reinterpret_cast<f32x4*>(xn + i * 4) = o;
+    }
+}
+
+static inline int stream_grid(long work_items) {
+    long b = (work_items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace cmk
+
+using namespace cmk;
+
+extern "C" int cmk_stem_conv_nchw3(const float* x, const float* w, const float* scale, const float* shift, float* y, int N, int H,
+                                   int W, int Cout, void* stream) {
+    if (!x || !w || !scale || !shift || !y) return fail(CMK_EINVAL, "stem: null pointer%s", "");
+    if (Cout <= 0 || (Cout & 15) || 256 % (Cout >> 4)) return fail(CMK_EINVAL, "stem: Cout (%s%ld) must be 16*2^k <= 4096", "", Cout);
+    int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    long total = (long)N * Ho * Wo;
+    int ppb = 256 / (Cout >> 4);
+    size_t lds = (size_t)29 * Cout * sizeof(float);
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), lds, (hipStream_t)stream, x, w, scale,
+                       shift, y, N, H, W, Ho, Wo, Cout);
+    return check_launch("stem_conv");
+}
+
+extern "C" int cmk_maxpool3x3s2_ceil_nhwc(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int H, int W, int C,
+                                          void* stream) {
+    if (!x || !y) return fail(CMK_EINVAL, "maxpool: null pointer%s", "");
+    if ((C & 3) || (x_cs & 3) || (x_co & 3) || (y_cs & 3) || (y_co & 3)) return fail(CMK_EINVAL, "maxpool: channels must be multiples of 4%s", "");
+    if (H < 3 || W < 3) return fail(CMK_EINVAL, "maxpool: input smaller than the window%s", "");
+    int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;  // ceil((H-3)/2)+1
+    if ((Ho - 1) * 2 >= H) --Ho;
+    if ((Wo - 1) * 2 >= W) --Wo;
+    long total = (long)N * Ho * Wo * (C >> 2);
+    hipLaunchKernelGGL(maxpool3_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, y, y_cs, y_co, N, H, W,
+                       Ho, Wo, C >> 2);
+    return check_launch("maxpool3");
+}
+
+extern "C" int cmk_ese_gate(const float* x, int x_cs, int x_co, const float* fc_w, const float* fc_b, float* gate, float* ws,
+                            int ws_chunks, int N, int HW, int C, void* stream) {
+    if (!x || !fc_w || !fc_b || !gate || !ws) return fail(CMK_EINVAL, "ese_gate: null pointer%s", "");
+    if ((C & 3) || (x_cs & 3) || (x_co & 3) || ws_chunks < 1) return fail(CMK_EINVAL, "ese_gate: bad shape%s", "");
+    int G = C >> 2;
+    int ppl = G >= 256 ? 1 : 256 / G;
+    size_t lds1 = (size_t)ppl * C * sizeof(float);
+    hipLaunchKernelGGL(ese_partial_kernel, dim3(ws_chunks, N), dim3(256), lds1, (hipStream_t)stream, x, x_cs, x_co, ws, HW, C, ws_chunks);
+    int rc = check_launch("ese_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ese_fc_kernel, dim3(cdiv(C, 64), N), dim3(256), (size_t)C * sizeof(float), (hipStream_t)stream, ws, fc_w, fc_b,
+                       gate, HW, C, ws_chunks);
+    return check_launch("ese_fc");
+}
+
+extern "C" int cmk_ese_scale(const float* x, int x_cs, int x_co, const float* gate, const float* identity, int id_cs, int id_co, float* y,
+                             int y_cs, int y_co, int N, int HW, int C, void* stream) {
+    if (!x || !gate || !y) return fail(CMK_EINVAL, "ese_scale: null pointer%s", "");
+    if ((C & 3) || (x_cs & 3) || (x_co & 3) || (y_cs & 3) || (y_co & 3) || (id_cs & 3) || (id_co & 3))
+        return fail(CMK_EINVAL, "ese_scale: channels must be multiples of 4%s", "");
+    long total = (long)N * HW * (C >> 2);
+    hipLaunchKernelGGL(ese_scale_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, gate, identity, id_cs,
+                       id_co, y, y_cs, y_co, N, HW, C >> 2);
+    return check_launch("ese_scale");
+}
+
+extern "C" int cmk_groupnorm_relu_nhwc(float* x, const float* gamma, const float* beta, double* ws, int ws_chunks, int N, int HW, int C,
+                                       int groups, float eps, void* stream) {
+    if (!x || !gamma || !beta || !ws) return fail(CMK_EINVAL, "groupnorm: null pointer%s", "");
+    if ((C & 3) || C > 1024 || groups < 1 || groups > 64 || C % groups || ((C / groups) & 3) || 256 % (C >> 2) || ws_chunks < 1)
+        return fail(CMK_EINVAL, "groupnorm: unsupported C/groups%s", "");
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(ws_chunks, N), dim3(256), 0, (hipStream_t)stream, x, ws, HW, C, groups, ws_chunks);
+    int rc = check_launch("gn_stats");
+    if (rc) return rc;
+    long total = (long)HW * (C >> 2);
+    int bpi = stream_grid(total);
+    if (bpi > 1024) bpi = 1024;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, ws, HW, C, groups, ws_chunks, eps,
+                       bpi);
+    return check_launch("gn_apply");
+}

@@ -1,0 +1,124 @@
+/*
+ * cmk.h — C ABI of libcmk_hip.so, the MI355X (gfx950) kernels under the CenterMask2 inference path.
+ *
+ * The reference (Zeng-Yan/centermask2) is pure Python; every arithmetic step of its path reaches native code
+ * through PyTorch / detectron2 / torchvision operators.  Each entry point below replaces one such operator
+ * call site (cited per function, paths relative to the reference root).  Conventions:
+ *   - the caller owns every buffer, including workspaces; the library never allocates, frees or synchronises;
+ *   - all pointers are device pointers; all launches go to the `stream` argument (a hipStream_t passed as void*);
+ *   - activations are NHWC float32; a tensor "view" is (pointer, channel stride `cs`, channel offset `co`), so a
+ *     conv can write straight into a slice of an OSA concat buffer (vovnet.py:324 never materialises);
+ *   - returns 0, or a negative CMK_E* code; cmk_last_error() gives the message (thread-local); nothing throws;
+ *   - stateless and re-entrant: one process per GPU each loads its own copy.
+ */
+#ifndef CMK_H
+#define CMK_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMK_OK 0
+#define CMK_EINVAL (-1)   /* bad argument / unsupported shape */
+#define CMK_ELAUNCH (-2)  /* HIP launch error */
+
+int cmk_version(void);                 /* ABI version, currently 1 */
+const char* cmk_arch(void);            /* "gfx950" */
+const char* cmk_last_error(void);
+
+/* ---- convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------------------------------------
+ * Replaces aten::conv2d (+ FrozenBN fold, bias, ReLU) at vovnet.py:205-236, fpn.py:27-35, d2 FPN lateral/output
+ * convs, fcos.py:169-200, sam.py:58-83, maskiou_head.py:81-93 and the Linear layers maskiou_head.py:89-91.
+ * Weights are pre-packed by cmk_pack_conv_weight_size/the host packer into [tap][Cin/16][cout_pad][16].
+ * y = act( conv(x) * scale[c] + shift[c] (+ residual) ),  act = ReLU on channels [0, relu_upto).              */
+typedef struct {
+    const float* x; int x_cs; int x_co;         /* input view, (N,H,W,Cin) */
+    const float* w;                             /* packed weights */
+    const float* scale; const float* shift;     /* per output channel, length >= Cout */
+    const float* res; int res_cs; int res_co;   /* optional residual view */
+    int res_mode;                               /* 0 none, 1 same resolution, 2 nearest-upsample x2 of (N,Hr,Wr,*) */
+    int Hr; int Wr;
+    float* y; int y_cs; int y_co;               /* output view, (N,Ho,Wo,Cout) */
+    int N; int H; int W; int Cin; int Cout;
+    int ksize;                                  /* 1 or 3 (padding ksize/2) */
+    int stride;                                 /* 1 or 2 */
+    int relu_upto;                              /* ReLU applied to output channels < relu_upto */
+    int in_relu;                                /* ReLU applied to the input while staging (fpn.py:34) */
+} cmk_conv_desc;
+int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
+/* number of floats of the packed layout for (Cout, Cin, k): taps * ceil(Cin/16) * cout_pad * 16 */
+int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize);
+int cmk_conv_cout_pad(int Cout);
+
+/* ---- stem_1: 3x3 stride-2 conv on the NCHW 3-channel image (vovnet.py:409), BN-folded, ReLU, NHWC out -------- */
+int cmk_stem_conv_nchw3(const float* x, const float* w /* [27][Cout] */, const float* scale, const float* shift,
+                        float* y, int N, int H, int W, int Cout, void* stream);
+
+/* ---- max pool k3 s2 ceil_mode, no padding (vovnet.py:349-350); k2 s2 (maskiou_head.py:93,108) ----------------- */
+int cmk_maxpool3x3s2_ceil_nhwc(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co,
+                               int N, int H, int W, int C, void* stream);
+
+/* ---- eSE (vovnet.py:247-260): gate = relu6(W * mean_HW(x) + b + 3) / 6 ; y = x * gate (+ identity) ------------
+ * ws: N * ese_chunks * C floats of workspace for the two-stage mean.                                        */
+int cmk_ese_gate(const float* x, int x_cs, int x_co, const float* fc_w /* [C][C] row = out */, const float* fc_b,
+                 float* gate /* N*C */, float* ws, int ws_chunks, int N, int HW, int C, void* stream);
+int cmk_ese_scale(const float* x, int x_cs, int x_co, const float* gate, const float* identity, int id_cs, int id_co,
+                  float* y, int y_cs, int y_co, int N, int HW, int C, void* stream);
+
+/* ---- GroupNorm(32) + ReLU in place (fcos.py:182-186) ---------------------------------------------------------
+ * ws: N * groups * gn_chunks * 2 doubles.                                                                    */
+int cmk_groupnorm_relu_nhwc(float* x, const float* gamma, const float* beta, double* ws, int ws_chunks,
+                            int N, int HW, int C, int groups, float eps, void* stream);
+
+/* ---- FCOS candidate selection + box decode (fcos_outputs.py:396-466) ------------------------------------------ */
+typedef struct {
+    const float* logits;   /* (N, HW, C) */
+    const float* regctr;   /* (N, HW, 5): relu(scale*bbox_pred) (4) , ctrness logit (1) */
+    int H; int W; int stride;
+} cmk_fcos_level;
+/* Per image i the candidates of all levels are appended in level order, location-major / class-minor
+ * (the order of torch.nonzero, fcos_outputs.py:429 and Instances.cat :391-392).
+ * cand_* have capacity `cap` rows per image; counts[i] receives the true number (may exceed cap => overflow). */
+int cmk_fcos_select(const cmk_fcos_level* levels, int num_levels, int N, int C, float pre_nms_thresh,
+                    float* cand_box /* N*cap*4 */, float* cand_score, int32_t* cand_cls, float* cand_loc /* N*cap*2 */,
+                    int32_t* counts /* N */, int32_t* block_counts /* workspace */, int64_t block_counts_len,
+                    int cap, void* stream);
+int64_t cmk_fcos_select_ws_len(const cmk_fcos_level* levels, int num_levels, int N, int C);
+
+/* ---- batched NMS + top-k (layers/ml_nms.py:93 -> d2 batched_nms; fcos_outputs.py:472-482) --------------------
+ * Stable descending sort by score (ties by candidate index), torchvision's coordinate trick
+ * (boxes + cls * (max_coord + 1)) for < 40000 candidates, per-class suppression otherwise, greedy IoU > thr,
+ * the first `topk` survivors are written.  sort_ws: 4 * N * cap uint32.                                       */
+int cmk_nms_topk(const float* cand_box, const float* cand_score, const int32_t* cand_cls, const float* cand_loc,
+                 const int32_t* counts, int N, int cap, float iou_thr, int topk,
+                 float* out_box /* N*topk*4 */, float* out_score, int64_t* out_cls, float* out_loc, int32_t* out_idx,
+                 int32_t* out_count /* N */, uint32_t* sort_ws, void* stream);
+
+/* ---- multi-level ROIAlignV2 with CenterMask's ratio level assignment (pooler.py:80-118,290-366) ---------------- */
+int cmk_roi_align_ratio(const float* const* feats /* host array of device pointers */, const int* feat_h, const int* feat_w,
+                        const float* scales, int num_levels, int min_level, int C,
+                        const float* boxes /* N*topk*4 */, const int32_t* counts, const float* img_area /* N */,
+                        int N, int topk, int out_size, int sampling_ratio,
+                        float* y, int y_cs /* (N*topk, out, out, y_cs) */, int32_t* out_level, void* stream);
+
+/* ---- SAG-Mask spatial attention (sam.py:23-28) in place ------------------------------------------------------- */
+int cmk_spatial_attention(float* x /* (R,S,S,C) */, const float* w /* [2][3][3] */, const int32_t* counts, int topk,
+                          int R, int S, int C, void* stream);
+
+/* ---- mask predictor for the predicted class only + sigmoid (sam.py:83,97; mask_head.py:202-208) ---------------
+ * deconv_out: (R, S, S, 4, C) = relu(deconv) laid out (dh,dw)-major; masks: (R, 2S, 2S).                     */
+int cmk_mask_predict(const float* deconv_out, const float* pw /* [classes][C] */, const float* pb,
+                     const int64_t* cls, const int32_t* counts, int topk, int R, int S, int C,
+                     float* masks, float* mask_logits_opt, void* stream);
+
+/* ---- maxpool 2x2 of the masks into channel `co` of the MaskIoU input (maskiou_head.py:108-112) ---------------- */
+int cmk_mask_pool_concat(const float* masks /* (R,2S,2S) */, float* y, int y_cs, int y_co, int R, int S, void* stream);
+
+/* ---- mask_scores = scores * iou[cls] (maskiou_head.py:50-60) -------------------------------------------------- */
+int cmk_mask_iou_score(const float* iou /* (R, classes_stride) */, int iou_cs, const float* scores, const int64_t* cls,
+                       float* mask_scores, int R, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,132 @@
+"""-m gpu: HIP kernels of the backbone/towers through the C ABI vs the oracle's torch fp32 ops (same seeded inputs).
+Tolerance: fp32 logits/features within 1e-3 abs (north_star); here 2e-4 * max|ref| for single ops."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from centermask2_amd import ops
+from centermask2_amd.ops import View
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _close(got, ref, rel=2e-4):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    bound = rel * max(1.0, ref.abs().max().item())
+    assert err <= bound, "max abs err {} > {}".format(err, bound)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride
+    (2, 20, 36, 128, 128, 3, 1),     # OSA2 layer shape class (WM2 WN4)
+    (1, 17, 23, 160, 160, 3, 1),     # WN5, ragged tile edges
+    (1, 25, 40, 224, 224, 3, 1),     # WN7 (stage5 map size)
+    (2, 13, 20, 192, 192, 3, 1),     # WN6
+    (1, 16, 16, 64, 64, 3, 1),       # WN2
+    (1, 9, 11, 256, 80, 3, 1),       # cls_logits: Cout 80 -> WN3 with masked columns
+    (1, 9, 11, 256, 5, 3, 1),        # bbox_pred+ctrness fused: WN1
+    (2, 14, 14, 256, 256, 3, 1),     # mask head (two N tiles)
+    (1, 21, 35, 64, 128, 3, 2),      # stem_3 class, stride 2, odd sizes
+    (2, 14, 14, 272, 256, 3, 2),     # maskiou conv4 class
+    (2, 13, 19, 768, 256, 1, 1),     # OSA concat 1x1
+    (1, 25, 40, 2144, 1024, 1, 1),   # largest concat
+    (1, 1, 37, 12544, 1024, 1, 1),   # maskiou_fc1 as 1x1 over 37 rows
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm_matches_torch(dev, case):
+    n, h, w, cin, cout, k, stride = case
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, k, k), 2, (2.0 / (cin * k * k)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(3)) + 0.5
+    shift = _rand((cout,), 4, 0.1)
+    ref = F.relu(F.conv2d(x, wt, None, stride=stride, padding=k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    pc = ops.PackedConv(wt, scale, shift, dev, stride=stride)
+    xv = ops.as_view(x.to(dev))
+    y = ops.conv_out(xv, pc, relu=True)
+    torch.cuda.synchronize()
+    _close(y.nchw(), ref)
+
+
+def test_conv_channel_views_residual_and_partial_relu(dev):
+    """Reads a channel slice of a wider buffer, writes into a slice of a concat buffer, adds an upsampled residual,
+    ReLU only on the first 4 channels (bbox_pred/ctrness epilogue)."""
+    n, h, w, cin, cout = 2, 10, 12, 32, 48
+    big = _rand((n, h, w, 80), 5).to(dev)
+    wt = _rand((cout, cin, 3, 3), 6, 0.1)
+    res = _rand((n, 5, 6, cout), 7).to(dev)
+    out = torch.full((n, h, w, 96), -7.0, device=dev)
+    pc = ops.PackedConv(wt, None, _rand((cout,), 8, 0.1), dev)
+    ops.conv2d(View(big, 16, cin), pc, View(out, 32, cout), relu_upto=4, res=View(res), res_upsample=True, in_relu=True)
+    torch.cuda.synchronize()
+    xin = F.relu(big[..., 16:48].permute(0, 3, 1, 2).cpu())
+    ref = F.conv2d(xin, wt, pc.shift.cpu(), padding=1) + F.interpolate(res.permute(0, 3, 1, 2).cpu(), scale_factor=2.0, mode="nearest")
+    ref[:, :4] = F.relu(ref[:, :4])
+    _close(out[..., 32:80].permute(0, 3, 1, 2), ref)
+    assert float(out[..., :32].max()) == -7.0 and float(out[..., 80:].min()) == -7.0   # neighbours untouched
+
+
+def test_conv_rejects_bad_arguments(dev, cmk_lib):
+    from centermask2_amd._lib import CmkError
+    x = torch.zeros((1, 4, 4, 24), device=dev)
+    pc = ops.PackedConv(torch.zeros((8, 16, 3, 3)), None, None, dev)
+    with pytest.raises((CmkError, AssertionError)):
+        ops.conv2d(View(x, 0, 24), pc, View(torch.zeros((1, 4, 4, 8), device=dev)))
+
+
+def test_stem_conv(dev):
+    x = _rand((2, 3, 37, 50), 11, 40.0)
+    wt = _rand((64, 3, 3, 3), 12, 0.2)
+    scale = torch.rand(64, generator=torch.Generator().manual_seed(13)) * 0.05 + 0.02
+    shift = _rand((64,), 14, 0.1)
+    ref = F.relu(F.conv2d(x, wt, None, stride=2, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    w27 = wt.permute(2, 3, 1, 0).reshape(27, 64).contiguous().to(dev)
+    y = ops.stem_conv(x.to(dev), w27, scale.to(dev), shift.to(dev))
+    torch.cuda.synchronize()
+    _close(y.nchw(), ref)
+
+
+@pytest.mark.parametrize("hw", [(200, 320), (25, 40), (9, 13), (3, 3), (4, 6)])
+def test_maxpool_ceil(dev, hw):
+    h, w = hw
+    x = _rand((2, 32, h, w), 21)
+    ref = F.max_pool2d(x, 3, 2, ceil_mode=True)
+    y = ops.maxpool3x3s2_ceil(ops.as_view(x.to(dev)))
+    torch.cuda.synchronize()
+    assert tuple(y.nchw().shape) == tuple(ref.shape)
+    assert torch.equal(y.nchw().cpu(), ref)          # max is exact
+
+
+@pytest.mark.parametrize("c,h,w", [(256, 40, 64), (512, 20, 32), (768, 10, 16), (1024, 5, 8), (1024, 3, 3)])
+def test_ese_with_identity(dev, c, h, w):
+    x = _rand((2, c, h, w), 31)
+    idn = _rand((2, c, h, w), 32)
+    fw = _rand((c, c, 1, 1), 33, c ** -0.5)
+    fb = _rand((c,), 34)
+    g = F.relu6(F.conv2d(F.adaptive_avg_pool2d(x, 1), fw, fb) + 3.0) / 6.0
+    ref = x * g + idn
+    xv, iv = ops.as_view(x.to(dev)), ops.as_view(idn.to(dev))
+    out = View(torch.empty_like(xv.t))
+    ops.ese(xv, fw.reshape(c, c).contiguous().to(dev), fb.to(dev), out, identity=iv)
+    torch.cuda.synchronize()
+    _close(out.nchw(), ref, 1e-5)
+
+
+@pytest.mark.parametrize("h,w", [(100, 160), (13, 20), (7, 10), (1, 1)])
+def test_groupnorm_relu(dev, h, w):
+    x = _rand((2, 256, h, w), 41, 3.0) + 1.5
+    gamma = torch.rand(256, generator=torch.Generator().manual_seed(42)) + 0.5
+    beta = _rand((256,), 43, 0.1)
+    ref = F.relu(F.group_norm(x, 32, gamma, beta, eps=1e-5))
+    t = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    ops.groupnorm_relu_(t, gamma.to(dev), beta.to(dev))
+    torch.cuda.synchronize()
+    _close(t.permute(0, 3, 1, 2), ref, 2e-5)
