@@ -1,0 +1,103 @@
+"""FPN (detectron2 surface; constructed at vovnet.py:547-554) and the FCOS top blocks (backbone/fpn.py:17-53).
+
+Kernels: lateral 1x1 convs run on the MFMA conv with the nearest-x2 top-down add fused into the epilogue
+(res_mode 2), output 3x3 convs and the stride-2 P6/P7 convs on the same kernel; `relu(p6)` (fpn.py:34) is applied
+while P7's input tile is staged.  Parameter names follow detectron2: fpn_lateral{3,4,5}, fpn_output{3,4,5},
+top_block.p6/p7.
+"""
+import math
+
+import torch
+from torch import nn
+
+from ... import ops
+from ...ops import View
+from ..base import Backbone, HipModule
+
+__all__ = ["FPN", "LastLevelP6P7", "LastLevelP6"]
+
+
+class LastLevelP6P7(nn.Module):
+    def __init__(self, in_channels, out_channels, in_features="res5"):
+        super().__init__()
+        self.num_levels = 2
+        self.in_feature = in_features
+        self.p6 = nn.Conv2d(in_channels, out_channels, 3, 2, 1)
+        self.p7 = nn.Conv2d(out_channels, out_channels, 3, 2, 1)
+
+
+class LastLevelP6(nn.Module):
+    def __init__(self, in_channels, out_channels, in_features="res5"):
+        super().__init__()
+        self.num_levels = 1
+        self.in_feature = in_features
+        self.p6 = nn.Conv2d(in_channels, out_channels, 3, 2, 1)
+
+
+class FPN(Backbone):
+    def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
+        super().__init__()
+        if norm != "":
+            raise NotImplementedError("FPN norm '{}' (the reference config uses '')".format(norm))
+        if fuse_type != "sum":
+            raise NotImplementedError("FPN fuse_type '{}' (the reference config uses 'sum')".format(fuse_type))
+        input_shapes = bottom_up.output_shape()
+        strides = [input_shapes[f].stride for f in in_features]
+        for a, b in zip(strides[:-1], strides[1:]):
+            assert b == 2 * a, "FPN input strides must double: {}".format(strides)
+        self._stages = [int(math.log2(s)) for s in strides]
+        for f, st in zip(in_features, self._stages):
+            self.add_module("fpn_lateral{}".format(st), nn.Conv2d(input_shapes[f].channels, out_channels, kernel_size=1))
+            self.add_module("fpn_output{}".format(st), nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1))
+        self.top_block = top_block
+        self.in_features = tuple(in_features)
+        self.bottom_up = bottom_up
+        self._out_feature_strides = {"p{}".format(st): s for st, s in zip(self._stages, strides)}
+        if top_block is not None:
+            for s in range(self._stages[-1], self._stages[-1] + top_block.num_levels):
+                self._out_feature_strides["p{}".format(s + 1)] = 2 ** (s + 1)
+        self._out_features = list(self._out_feature_strides.keys())
+        self._out_feature_channels = {k: out_channels for k in self._out_features}
+        self._size_divisibility = strides[-1]
+        self._fuse_type = fuse_type
+
+    @property
+    def size_divisibility(self):
+        return self._size_divisibility
+
+    def _build_packed(self, dev):
+        P = {}
+        for st in self._stages:
+            lat, out = getattr(self, "fpn_lateral{}".format(st)), getattr(self, "fpn_output{}".format(st))
+            P["lat{}".format(st)] = ops.PackedConv(lat.weight, None, lat.bias, dev)
+            P["out{}".format(st)] = ops.PackedConv(out.weight, None, out.bias, dev)
+        if self.top_block is not None:
+            P["p6"] = ops.PackedConv(self.top_block.p6.weight, None, self.top_block.p6.bias, dev, stride=2)
+            if self.top_block.num_levels == 2:
+                P["p7"] = ops.PackedConv(self.top_block.p7.weight, None, self.top_block.p7.bias, dev, stride=2)
+        return P
+
+    def forward_views(self, x):
+        P = self.packed()
+        bu = self.bottom_up.forward_views(x)
+        results = {}
+        prev = None
+        for f, st in zip(reversed(self.in_features), reversed(self._stages)):
+            c = bu[f]
+            if prev is not None and (prev.t.shape[1] * 2 != c.t.shape[1] or prev.t.shape[2] * 2 != c.t.shape[2]):
+                raise ValueError("FPN: feature {} is {}x{}, not twice the level above ({}x{}); pad the input to a multiple of {}"
+                                 .format(f, c.t.shape[1], c.t.shape[2], prev.t.shape[1], prev.t.shape[2], self._size_divisibility))
+            prev = ops.conv_out(c, P["lat{}".format(st)], res=prev, res_upsample=prev is not None)  # lateral + up2(top-down)
+            results["p{}".format(st)] = ops.conv_out(prev, P["out{}".format(st)])
+        if self.top_block is not None:
+            src_name = self.top_block.in_feature
+            src = bu[src_name] if src_name in bu else results[src_name]
+            top = self._stages[-1]
+            p6 = ops.conv_out(src, P["p6"])
+            results["p{}".format(top + 1)] = p6
+            if self.top_block.num_levels == 2:
+                results["p{}".format(top + 2)] = ops.conv_out(p6, P["p7"], in_relu=True)     # p7(relu(p6)), fpn.py:34
+        return {k: results[k] for k in self._out_features}
+
+    def forward(self, x):
+        return {k: v.nchw() for k, v in self.forward_views(x).items()}

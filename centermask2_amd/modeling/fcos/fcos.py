@@ -1,0 +1,204 @@
+"""FCOS proposal generator on HIP kernels (mirrors centermask2/centermask/modeling/fcos/fcos.py and the inference
+half of fcos_outputs.py).
+
+  FCOSHead.forward  fcos.py:222-240   towers = [conv3x3(bias) -> GroupNorm(32) -> ReLU] x4 per branch, on the MFMA conv
+                                      kernel + the GN/ReLU kernel; cls_logits as one conv (NHWC output is already the
+                                      (N, HW, C) layout the decode wants); bbox_pred and ctrness fused into ONE 256->5
+                                      conv whose epilogue applies relu(scale_l * .) to the 4 box channels only.
+  predict_proposals fcos_outputs.py:372-495  -> ops.fcos_select (threshold/compact/decode) + ops.nms_topk.
+State-dict keys equal the reference's (cls_tower.{0,1,3,4,...}, bbox_tower.*, cls_logits, bbox_pred, ctrness, scales.N.scale).
+"""
+import math
+from typing import Dict, List
+
+import torch
+from torch import nn
+
+from ... import ops
+from ...ops import View
+from ...registry import PROPOSAL_GENERATOR_REGISTRY
+from ...structures import Boxes, Instances, ShapeSpec
+from ..base import HipModule
+
+__all__ = ["FCOS", "FCOSHead", "Scale"]
+
+
+class Scale(nn.Module):
+    def __init__(self, init_value=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.FloatTensor([init_value]))
+
+
+class FCOSHead(HipModule):
+    def __init__(self, cfg, input_shape: List[ShapeSpec]):
+        super().__init__()
+        self.num_classes = cfg.MODEL.FCOS.NUM_CLASSES
+        self.fpn_strides = cfg.MODEL.FCOS.FPN_STRIDES
+        if cfg.MODEL.FCOS.USE_DEFORMABLE:
+            raise NotImplementedError("MODEL.FCOS.USE_DEFORMABLE (off in the reference config, defaults.py:41)")
+        self.norm = None if cfg.MODEL.FCOS.NORM == "none" else cfg.MODEL.FCOS.NORM
+        if self.norm not in (None, "GN"):
+            raise NotImplementedError("MODEL.FCOS.NORM={}".format(self.norm))
+        head_configs = {"cls": cfg.MODEL.FCOS.NUM_CLS_CONVS, "bbox": cfg.MODEL.FCOS.NUM_BOX_CONVS, "share": cfg.MODEL.FCOS.NUM_SHARE_CONVS}
+        in_channels = [s.channels for s in input_shape]
+        assert len(set(in_channels)) == 1, "Each level must have the same channel!"
+        in_channels = in_channels[0]
+        self.in_channels = in_channels
+        for head, num_convs in head_configs.items():
+            tower = []
+            for _ in range(num_convs):
+                tower.append(nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1, bias=True))
+                if self.norm == "GN":
+                    tower.append(nn.GroupNorm(32, in_channels))
+                tower.append(nn.ReLU())
+            self.add_module("{}_tower".format(head), nn.Sequential(*tower))
+        self.cls_logits = nn.Conv2d(in_channels, self.num_classes, kernel_size=3, stride=1, padding=1)
+        self.bbox_pred = nn.Conv2d(in_channels, 4, kernel_size=3, stride=1, padding=1)
+        self.ctrness = nn.Conv2d(in_channels, 1, kernel_size=3, stride=1, padding=1)
+        self.scales = nn.ModuleList([Scale(init_value=1.0) for _ in self.fpn_strides]) if cfg.MODEL.FCOS.USE_SCALE else None
+        for modules in [self.cls_tower, self.bbox_tower, self.share_tower, self.cls_logits, self.bbox_pred, self.ctrness]:
+            for l in modules.modules():
+                if isinstance(l, nn.Conv2d):
+                    torch.nn.init.normal_(l.weight, std=0.01)
+                    torch.nn.init.constant_(l.bias, 0)
+        prior_prob = cfg.MODEL.FCOS.PRIOR_PROB
+        torch.nn.init.constant_(self.cls_logits.bias, -math.log((1 - prior_prob) / prior_prob))
+
+    def _tower_packed(self, tower: nn.Sequential, dev):
+        out = []
+        mods = list(tower)
+        i = 0
+        while i < len(mods):
+            conv = mods[i]
+            assert isinstance(conv, nn.Conv2d)
+            gn = mods[i + 1] if (i + 1 < len(mods) and isinstance(mods[i + 1], nn.GroupNorm)) else None
+            pc = ops.PackedConv(conv.weight, None, conv.bias, dev)
+            if gn is not None:
+                out.append((pc, gn.weight.detach().float().contiguous().to(dev), gn.bias.detach().float().contiguous().to(dev), gn.eps, gn.num_groups))
+                i += 3
+            else:
+                out.append((pc, None, None, 0.0, 0))
+                i += 2
+        return out
+
+    def _build_packed(self, dev):
+        P = {"share": self._tower_packed(self.share_tower, dev), "cls": self._tower_packed(self.cls_tower, dev),
+             "bbox": self._tower_packed(self.bbox_tower, dev)}
+        P["cls_logits"] = ops.PackedConv(self.cls_logits.weight, None, self.cls_logits.bias, dev)
+        # bbox_pred (4) + ctrness (1) share one conv; per level: (acc + b) * s = acc * s + b * s on the box channels
+        w = torch.cat([self.bbox_pred.weight.detach().float().cpu(), self.ctrness.weight.detach().float().cpu()], 0)
+        b = torch.cat([self.bbox_pred.bias.detach().float().cpu(), self.ctrness.bias.detach().float().cpu()], 0)
+        base = ops.PackedConv(w, None, None, dev)
+        P["regctr"] = []
+        for l in range(len(self.fpn_strides)):
+            s = float(self.scales[l].scale.detach().float().cpu()) if self.scales is not None else 1.0
+            pc = ops.PackedConv.__new__(ops.PackedConv)
+            pc.__dict__.update(base.__dict__)
+            sc = torch.tensor([s, s, s, s, 1.0], dtype=torch.float32)
+            pc.scale = sc.to(dev)
+            pc.shift = (b * sc).to(dev)
+            P["regctr"].append(pc)
+        return P
+
+    @staticmethod
+    def _run_tower(x: View, tower) -> View:
+        for pc, gamma, beta, eps, groups in tower:
+            if gamma is None:
+                x = ops.conv_out(x, pc, relu=True)
+            else:
+                x = ops.conv_out(x, pc)
+                ops.groupnorm_relu_(x.t, gamma, beta, groups, eps)
+        return x
+
+    def forward_views(self, feats: List[View]):
+        """-> (logits[l] (N,H,W,C) NHWC, regctr[l] (N,H,W,5) = [relu(scale_l*bbox_pred) x4, ctrness logit])."""
+        P = self.packed()
+        logits, regctr = [], []
+        for l, f in enumerate(feats):
+            f = self._run_tower(f, P["share"])
+            cls_t = self._run_tower(f, P["cls"])
+            box_t = self._run_tower(f, P["bbox"])
+            logits.append(ops.conv_out(cls_t, P["cls_logits"]).t)
+            regctr.append(ops.conv_out(box_t, P["regctr"][l], relu_upto=4).t)       # fcos.py:233-238
+        return logits, regctr
+
+    def forward(self, x: List[torch.Tensor]):
+        """Reference signature (fcos.py:222-240): NCHW logits, bbox_reg, ctrness, bbox_towers([])."""
+        logits, regctr = self.forward_views([ops.as_view(f) for f in x])
+        lg = [t.permute(0, 3, 1, 2) for t in logits]
+        reg = [t[..., :4].permute(0, 3, 1, 2) for t in regctr]
+        ctr = [t[..., 4:5].permute(0, 3, 1, 2) for t in regctr]
+        return lg, reg, ctr, []
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class FCOS(HipModule):
+    def __init__(self, cfg, input_shape: Dict[str, ShapeSpec]):
+        super().__init__()
+        self.in_features = cfg.MODEL.FCOS.IN_FEATURES
+        self.fpn_strides = cfg.MODEL.FCOS.FPN_STRIDES
+        self.pre_nms_thresh_test = cfg.MODEL.FCOS.INFERENCE_TH_TEST
+        self.pre_nms_topk_test = cfg.MODEL.FCOS.PRE_NMS_TOPK_TEST      # unused by the fork (fcos_outputs.py:444-449)
+        self.nms_thresh = cfg.MODEL.FCOS.NMS_TH
+        self.post_nms_topk_test = cfg.MODEL.FCOS.POST_NMS_TOPK_TEST
+        self.thresh_with_ctr = cfg.MODEL.FCOS.THRESH_WITH_CTR
+        if self.thresh_with_ctr:
+            raise NotImplementedError("MODEL.FCOS.THRESH_WITH_CTR=True (False in the reference, defaults.py:34)")
+        if not (1 <= self.post_nms_topk_test <= 64):
+            raise NotImplementedError("POST_NMS_TOPK_TEST must be in [1, 64] (the NMS kernel keeps its survivors in one wave)")
+        self.mask_on = cfg.MODEL.MASK_ON
+        self.fcos_head = FCOSHead(cfg, [input_shape[f] for f in self.in_features])
+        # candidates per image the workspaces are sized for; the reference is unbounded (no pre-NMS top-k), so an
+        # overflow is detected from the device-side count and reported, never silently truncated.
+        self.candidate_capacity = 131072
+
+    def _build_packed(self, dev):
+        return {}
+
+    def compute_locations(self, features):
+        """fcos.py:120-144 (kept for API parity; the decode kernel derives locations from the index)."""
+        locations = []
+        for level, feature in enumerate(features):
+            h, w = feature.size()[-2:]
+            s = self.fpn_strides[level]
+            shifts_x = torch.arange(0, w * s, step=s, dtype=torch.float32, device=feature.device)
+            shifts_y = torch.arange(0, h * s, step=s, dtype=torch.float32, device=feature.device)
+            shift_y, shift_x = torch.meshgrid(shifts_y, shifts_x, indexing="ij")
+            locations.append(torch.stack((shift_x.reshape(-1), shift_y.reshape(-1)), dim=1) + s // 2)
+        return locations
+
+    def forward_padded(self, features):
+        """Device-only path: returns (detections dict padded to (N, topk), candidates dict).  No host sync."""
+        feats = [ops.as_view(features[f]) for f in self.in_features]
+        logits, regctr = self.fcos_head.forward_views(feats)
+        cand = ops.fcos_select(logits, regctr, self.fpn_strides, self.pre_nms_thresh_test, self.candidate_capacity)
+        det = ops.nms_topk(cand, self.nms_thresh, self.post_nms_topk_test)
+        det["cand_counts"] = cand["counts"]
+        return det, cand
+
+    def forward(self, images, features, gt_instances=None):
+        """fcos.py:61-118 (inference branch): -> (list[Instances], {}).  `images` needs len() and .image_sizes."""
+        if self.training:
+            raise NotImplementedError("training is out of scope of the MI355X inference path")
+        det, _ = self.forward_padded(features)
+        return instances_from_padded(det, images.image_sizes, self.candidate_capacity), {}
+
+
+def instances_from_padded(det: dict, image_sizes, cap=None) -> List[Instances]:
+    """One host sync: read the per-image counts, slice the padded device buffers into Instances
+    (fields of fcos_outputs.py:458-462).  The padded buffers ride along for CenterROIHeads."""
+    counts = det["counts"].cpu().tolist()
+    if cap is not None:
+        over = det["cand_counts"].cpu().tolist()
+        if max(over) > cap:
+            raise RuntimeError("FCOS produced {} candidates > capacity {}; raise FCOS.candidate_capacity".format(max(over), cap))
+    out = []
+    for i, k in enumerate(counts):
+        inst = Instances(tuple(image_sizes[i]))
+        inst.pred_boxes = Boxes(det["box"][i, :k])
+        inst.scores = det["score"][i, :k]
+        inst.pred_classes = det["cls"][i, :k]
+        inst.locations = det["loc"][i, :k]
+        inst._cmk_padded = (det, i)
+        out.append(inst)
+    return out

@@ -200,3 +200,108 @@ def groupnorm_relu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gr
     ws = torch.empty((n, groups, chunks, 2), dtype=torch.float64, device=x.device)
     check(lib.cmk_groupnorm_relu_nhwc(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), chunks, n, hw, c, groups,
                                       eps, _stream()), "cmk_groupnorm_relu_nhwc")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# FCOS post-head: candidate selection, sort + NMS + top-k (all counts stay on the device)
+# ---------------------------------------------------------------------------------------------------------------
+def fcos_select(logits: Sequence[torch.Tensor], regctr: Sequence[torch.Tensor], strides: Sequence[int], thresh: float, cap: int):
+    """logits[l]: (N,H,W,C) dense NHWC; regctr[l]: (N,H,W,5).  Returns dict of candidate buffers (N,cap,...) + counts (N)."""
+    lib = _lib.load()
+    n, c = logits[0].shape[0], logits[0].shape[3]
+    dev = logits[0].device
+    _need_gpu(logits[0], "fcos_select")
+    nl = len(logits)
+    lv = (FcosLevel * nl)()
+    for i, (lg, rc, s) in enumerate(zip(logits, regctr, strides)):
+        assert lg.is_contiguous() and rc.is_contiguous() and rc.shape[3] == 5 and lg.shape[:3] == rc.shape[:3]
+        lv[i].logits, lv[i].regctr = lg.data_ptr(), rc.data_ptr()
+        lv[i].H, lv[i].W, lv[i].stride = lg.shape[1], lg.shape[2], int(s)
+    wslen = lib.cmk_fcos_select_ws_len(lv, nl, n, c)
+    assert wslen > 0
+    ws = torch.empty((wslen,), dtype=torch.int32, device=dev)
+    out = dict(box=torch.empty((n, cap, 4), dtype=torch.float32, device=dev),
+               score=torch.empty((n, cap), dtype=torch.float32, device=dev),
+               cls=torch.empty((n, cap), dtype=torch.int32, device=dev),
+               loc=torch.empty((n, cap, 2), dtype=torch.float32, device=dev),
+               counts=torch.empty((n,), dtype=torch.int32, device=dev), cap=cap)
+    check(lib.cmk_fcos_select(lv, nl, n, c, float(thresh), out["box"].data_ptr(), out["score"].data_ptr(), out["cls"].data_ptr(),
+                              out["loc"].data_ptr(), out["counts"].data_ptr(), ws.data_ptr(), wslen, cap, _stream()), "cmk_fcos_select")
+    return out
+
+
+def nms_topk(cand: dict, iou_thr: float, topk: int):
+    lib = _lib.load()
+    n, cap = cand["score"].shape
+    dev = cand["score"].device
+    out = dict(box=torch.empty((n, topk, 4), dtype=torch.float32, device=dev),
+               score=torch.empty((n, topk), dtype=torch.float32, device=dev),
+               cls=torch.empty((n, topk), dtype=torch.int64, device=dev),
+               loc=torch.empty((n, topk, 2), dtype=torch.float32, device=dev),
+               idx=torch.empty((n, topk), dtype=torch.int32, device=dev),
+               counts=torch.empty((n,), dtype=torch.int32, device=dev))
+    ws = torch.empty((n, 4, cap), dtype=torch.int32, device=dev)
+    check(lib.cmk_nms_topk(cand["box"].data_ptr(), cand["score"].data_ptr(), cand["cls"].data_ptr(), cand["loc"].data_ptr(),
+                           cand["counts"].data_ptr(), n, cap, float(iou_thr), topk, out["box"].data_ptr(), out["score"].data_ptr(),
+                           out["cls"].data_ptr(), out["loc"].data_ptr(), out["idx"].data_ptr(), out["counts"].data_ptr(),
+                           ws.data_ptr(), _stream()), "cmk_nms_topk")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ROI heads
+# ---------------------------------------------------------------------------------------------------------------
+def roi_align_ratio(feats: Sequence[View], scales: Sequence[float], boxes: torch.Tensor, counts: torch.Tensor,
+                    img_area: torch.Tensor, out_size: int, sampling_ratio: int, y: torch.Tensor, min_level: int):
+    """feats: dense NHWC levels; boxes (N,topk,4); y: (N*topk,out,out,y_cs) receives channels [0,C).  Returns levels (N*topk) int32."""
+    lib = _lib.load()
+    nl = len(feats)
+    n, topk = boxes.shape[0], boxes.shape[1]
+    c = feats[0].c
+    ptrs = (ctypes.c_void_p * nl)()
+    hs, ws_ = (ctypes.c_int * nl)(), (ctypes.c_int * nl)()
+    sc = (ctypes.c_float * nl)()
+    for i, f in enumerate(feats):
+        assert f.co == 0 and f.cs == c, "roi_align needs dense NHWC features"
+        ptrs[i] = f.t.data_ptr()
+        hs[i], ws_[i] = f.t.shape[1], f.t.shape[2]
+        sc[i] = float(scales[i])
+    levels = torch.empty((n * topk,), dtype=torch.int32, device=boxes.device)
+    check(lib.cmk_roi_align_ratio(ptrs, hs, ws_, sc, nl, min_level, c, boxes.data_ptr(), counts.data_ptr(), img_area.data_ptr(),
+                                  n, topk, out_size, sampling_ratio, y.data_ptr(), y.shape[3], levels.data_ptr(), _stream()),
+          "cmk_roi_align_ratio")
+    return levels
+
+
+def spatial_attention_(x: torch.Tensor, w: torch.Tensor, counts: torch.Tensor, topk: int) -> None:
+    lib = _lib.load()
+    r, s, _, c = x.shape
+    check(lib.cmk_spatial_attention(x.data_ptr(), w.data_ptr(), counts.data_ptr(), topk, r, s, c, _stream()), "cmk_spatial_attention")
+
+
+def mask_predict(dec: torch.Tensor, pw: torch.Tensor, pb: torch.Tensor, cls: torch.Tensor, counts: torch.Tensor, topk: int,
+                 want_logits: bool = False):
+    """dec: (R,S,S,4*C) relu(deconv); returns masks (R,1,2S,2S) [, selected-class logits (R,2S,2S)]."""
+    lib = _lib.load()
+    r, s = dec.shape[0], dec.shape[1]
+    c = dec.shape[3] // 4
+    masks = torch.empty((r, 1, 2 * s, 2 * s), dtype=torch.float32, device=dec.device)
+    logits = torch.empty((r, 2 * s, 2 * s), dtype=torch.float32, device=dec.device) if want_logits else None
+    check(lib.cmk_mask_predict(dec.data_ptr(), pw.data_ptr(), pb.data_ptr(), cls.data_ptr(), counts.data_ptr(), topk, r, s, c,
+                               masks.data_ptr(), logits.data_ptr() if want_logits else None, _stream()), "cmk_mask_predict")
+    return (masks, logits) if want_logits else masks
+
+
+def mask_pool_concat_(masks: torch.Tensor, y: torch.Tensor, y_co: int) -> None:
+    lib = _lib.load()
+    r, s = y.shape[0], y.shape[1]
+    check(lib.cmk_mask_pool_concat(masks.data_ptr(), y.data_ptr(), y.shape[3], y_co, r, s, _stream()), "cmk_mask_pool_concat")
+
+
+def mask_iou_score(iou: torch.Tensor, scores: torch.Tensor, cls: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    r = iou.shape[0]
+    out = torch.empty((r,), dtype=torch.float32, device=iou.device)
+    check(lib.cmk_mask_iou_score(iou.data_ptr(), iou.shape[1], scores.data_ptr(), cls.data_ptr(), out.data_ptr(), r, _stream()),
+          "cmk_mask_iou_score")
+    return out

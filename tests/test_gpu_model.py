@@ -1,0 +1,91 @@
+"""-m gpu: the plugins end to end against the fixtures the reference's own modules produced (tests/golden).
+Tolerances: features/logits 1e-3 abs-or-rel (north_star "within 1e-3 fp32"), labels/locations exact."""
+import pytest
+import torch
+
+from .helpers import build_gpu_model, close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    return build_gpu_model()[0]
+
+
+def test_vovnet_odd_size_matches_reference(dev, model):
+    g = golden("vovnet_odd")
+    out = model.backbone.bottom_up(g["x"].to(dev))
+    torch.cuda.synchronize()
+    for k in ("stage3", "stage4", "stage5"):
+        assert tuple(out[k].shape) == tuple(g[k].shape)
+        close(out[k], g[k], 1e-4, k)
+
+
+def test_backbone_fpn_matches_reference(dev, model):
+    g = golden("backbone_small")
+    out = model.backbone(g["x"].to(dev))
+    torch.cuda.synchronize()
+    assert list(out.keys()) == ["p3", "p4", "p5", "p6", "p7"]
+    for k in out:
+        close(out[k], g[k], 1e-4, k)
+    shp = model.backbone.output_shape()
+    assert shp["p3"].stride == 8 and shp["p7"].stride == 128 and shp["p5"].channels == 256 and model.backbone.size_divisibility == 32
+
+
+def test_fcos_head_matches_reference(dev, model):
+    g, bb = golden("fcos_small"), golden("backbone_small")
+    feats = [bb[k].to(dev) for k in ("p3", "p4", "p5", "p6", "p7")]
+    head = model.proposal_generator.fcos_head
+    shift = float(g["cls_bias_shift"])
+    head.cls_logits.bias.data += shift
+    head.invalidate_packed()
+    try:
+        lg, reg, ctr, _ = head(feats)
+        torch.cuda.synchronize()
+    finally:
+        head.cls_logits.bias.data -= shift
+        head.invalidate_packed()
+    for l in range(5):
+        close(lg[l], g["logits"][l], 1e-3, "logits")
+        close(reg[l], g["reg"][l], 1e-3, "reg")
+        close(ctr[l], g["ctr"][l], 1e-3, "ctr")
+
+
+def _probe_check(t_nchw, p, tol, what):
+    flat = t_nchw.contiguous().reshape(-1).cpu()
+    assert tuple(t_nchw.shape) == tuple(p["shape"].tolist()), what
+    close(flat[p["idx"]], p["val"], tol, what + " probe")
+    close(flat.double().mean().float().reshape(1), p["mean"].reshape(1), tol, what + " mean")
+
+
+def test_end_to_end_800x1280_matches_reference(dev, model):
+    """BASELINE config 1 shape: two 800x1280 images through backbone -> FCOS -> CenterROIHeads; compares with what the
+    reference produced for the same seeded weights/images."""
+    from centermask2_amd import synthetic as S
+    from centermask2_amd.structures import FakeImageList
+    g = golden("e2e_800x1280")
+    x = S.make_synthetic_images(2, 800, 1280, seed0=int(g["image_seed0"])).to(dev)
+    sizes = [(800, 1280), (800, 1280)]
+    feats = model.backbone(x)
+    for k in ("p3", "p4", "p5", "p6", "p7"):
+        _probe_check(feats[k], g[k], 1e-3, k)
+    lg, reg, ctr, _ = model.proposal_generator.fcos_head([feats[k] for k in ("p3", "p4", "p5", "p6", "p7")])
+    for l in range(5):
+        _probe_check(lg[l], g["logits{}".format(l)], 1e-3, "logits{}".format(l))
+        _probe_check(reg[l], g["reg{}".format(l)], 1e-3, "reg{}".format(l))
+        _probe_check(ctr[l], g["ctr{}".format(l)], 1e-3, "ctr{}".format(l))
+    res = model.inference(FakeImageList(x, sizes), do_preprocess=False, do_postprocess=False)
+    torch.cuda.synchronize()
+    for i in range(2):
+        r, inst = g["img{}".format(i)], res[i]
+        assert len(inst) == r["scores"].shape[0]
+        assert torch.equal(inst.pred_classes.cpu(), r["classes"]), "labels differ"
+        assert torch.equal(inst.locations.cpu(), r["locations"]), "ROI locations differ"
+        close(inst.pred_boxes.tensor, r["boxes"], 1e-3 / 1280, "boxes")
+        close(inst.scores, r["scores"], 1e-4, "scores")
+        close(inst.pred_masks, r["pred_masks"], 1e-3, "pred_masks")
+        close(inst.mask_scores, r["mask_scores"], 1e-3, "mask_scores")
+        assert inst.pred_classes.dtype == torch.int64 and tuple(inst.pred_masks.shape[1:]) == (1, 28, 28)
+    t = model.forward_tensor(x[:1], hw=[(800, 1280)])
+    assert [tuple(v.shape[1:]) for v in t] == [(2,), (), (4,), (), (1, 28, 28), ()]
