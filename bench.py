@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""CenterMask2 V2-39-eSE-FPN inference throughput on MI355X (BASELINE.json metric: images/sec at 3x800x1280).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the whole hot path (VoVNetV2-39-eSE + FPN -> FCOS head/decode/NMS/top-50 -> CenterROIHeads with
+SAG-Mask + MaskIoU) over one batch of 8 synthetic 3x800x1280 images per GPU, inputs already resident in HBM,
+results left as padded device buffers.  Images shard across ranks (weak scaling, no data-path collective inside the
+model); each step ends with one RCCL all-gather of the fixed-stride per-image results.
+Rank 0 prints ONE JSON line, with
+  roofline     — the dominant kernel (the fp32-MFMA implicit-GEMM conv) measured live with HIP events on the launch stream;
+  cpu_baseline — the oracle (CPU restatement of the reference path, kind "port") timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0
+
+
+def build(conv_body, device):
+    from centermask2_amd import synthetic as S
+    from centermask2_amd.config import config_path, get_cfg
+    from centermask2_amd.modeling import build_model
+    cfg = get_cfg()
+    cfg.merge_from_file(config_path("centermask_V_39_eSE_FPN_ms_3x.yaml" if conv_body == "V-39-eSE" else "centermask_V_99_eSE_FPN_ms_3x.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", str(device), "MODEL.VOVNET.CONV_BODY", conv_body])
+    cfg.freeze()
+    sd = S.make_synthetic_state_dict(conv_body, 0)
+    model = build_model(cfg).eval()
+    model.load_state_dict(sd)
+    return model, sd
+
+
+def pack_results(out):
+    """Fixed-stride per-image record for the all-gather: 50 x (box4, score, mask_score, loc2, cls, mask784) + count."""
+    n, k = out["score"].shape
+    rec = torch.cat([out["box"].reshape(n, -1), out["score"], out["mask_scores"], out["loc"].reshape(n, -1),
+                     out["cls"].float(), out["pred_masks"].reshape(n, -1), out["counts"].float().reshape(n, 1)], dim=1)
+    return rec.contiguous()
+
+
+def roofline_leg(model, x, sizes):
+    """One instrumented step: HIP events (torch's current stream == the launch stream) around every conv launch."""
+    from centermask2_amd import ops
+    ops.PROFILE = []
+    with torch.no_grad():
+        model.inference_padded(x, sizes)
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for key, fl, by, e0, e1, shape in prof:
+        a = agg.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        a["ms"] += e0.elapsed_time(e1)
+        a["flops"] += fl
+        a["bytes"] += by
+        a["launches"] += 1
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    d = agg[dom]
+    total_ms = sum(a["ms"] for a in agg.values())
+    roof = {
+        "bound": "mfma", "kernel": dom, "achieved": round(d["flops"] / d["ms"] / 1e9, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(d["flops"] / d["ms"] / 1e9 / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+        "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+        "alg_flops_per_launch": round(d["flops"] / d["launches"] / 1e9, 3), "alg_GBps": round(d["bytes"] / d["ms"] / 1e6, 1),
+        "hbm_frac": round(d["bytes"] / d["ms"] / 1e6 / PEAK_HBM_GBS, 4),
+        "all_convs": {"ms_per_step": round(total_ms, 3), "TFLOP/s": round(sum(a["flops"] for a in agg.values()) / total_ms / 1e9, 2),
+                      "alg_GBps": round(sum(a["bytes"] for a in agg.values()) / total_ms / 1e6, 1)},
+        "per_kernel": {k: {"ms": round(a["ms"], 3), "TFLOP/s": round(a["flops"] / a["ms"] / 1e9, 1), "launches": a["launches"]}
+                       for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+    }
+    return roof
+
+
+def cpu_baseline_leg(sd, conv_body, budget_s=25.0):
+    """The oracle (plain PyTorch CPU ops + C nms/roi_align) on the same seeded workload, bounded to ~budget_s."""
+    from centermask2_amd import synthetic as S
+    from oracle import centermask_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    x = S.make_synthetic_images(1, 800, 1280, seed0=1234)
+    t0 = time.time()
+    O.centermask_inference(sd, x, [(800, 1280)], conv_body)        # warm-up (also pages the weights in)
+    warm = time.time() - t0
+    n, t_used = 0, 0.0
+    while n < 8 and (n == 0 or t_used + t_used / n < budget_s - warm):
+        xi = S.make_synthetic_images(1, 800, 1280, seed0=1234, first=n + 1)
+        t0 = time.time()
+        O.centermask_inference(sd, xi, [(800, 1280)], conv_body)
+        t_used += time.time() - t0
+        n += 1
+    return {"value": round(n / t_used, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "{} image(s) 3x800x1280 (batch 1, full model incl. NMS/ROI heads) after 1 warm-up, torch {} CPU fp32".format(n, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--body", default="V-39-eSE")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # RCCL over xGMI
+
+    from centermask2_amd import synthetic as S
+    model, sd = build(args.body, dev)
+    B = args.batch
+    x = S.make_synthetic_images(B, 800, 1280, seed0=1234, first=rank * B).to(dev)   # resident in HBM before timing
+    sizes = [(800, 1280)] * B
+
+    gathered = None
+
+    def step_eager():
+        nonlocal gathered
+        out = model.inference_padded(x, sizes)
+        rec = pack_results(out)
+        if world > 1:
+            if gathered is None:
+                gathered = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=dev)
+            dist.all_gather_into_tensor(gathered, rec)
+        return out, rec
+
+    use_graph = not args.no_graph
+    graph = None
+    with torch.no_grad():
+        out, rec = step_eager()            # first call: packs weights, sets kernel attributes
+        torch.cuda.synchronize()
+        if use_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    model.inference_padded(x, sizes)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    g_out = model.inference_padded(x, sizes)
+                    g_rec = pack_results(g_out)
+                torch.cuda.synchronize()
+            except Exception as e:      # capture is an optimisation; the eager path is the same kernels
+                if rank == 0:
+                    print("graph capture failed ({}: {}); running eagerly".format(type(e).__name__, str(e)[:200]), file=sys.stderr)
+                graph = None
+
+        def step():
+            nonlocal gathered
+            if graph is None:
+                return step_eager()
+            graph.replay()
+            if world > 1:
+                if gathered is None:
+                    gathered = torch.empty((world * g_rec.shape[0], g_rec.shape[1]), dtype=g_rec.dtype, device=dev)
+                dist.all_gather_into_tensor(gathered, g_rec)
+            return g_out, g_rec
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, rec = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        cand = out["cand_counts"].cpu().tolist()
+        cap = model.proposal_generator.candidate_capacity
+        assert max(cand) <= cap, "candidate overflow {} > {}".format(max(cand), cap)
+        dets = out["counts"].cpu().tolist()
+
+        result = None
+        if rank == 0:
+            roof = roofline_leg(model, x, sizes)
+            cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline_leg(sd, args.body)
+            total_images = world * B * args.steps
+            result = {
+                "metric": "images/sec whole-node (V2-39-eSE 3x800x1280)" if args.body == "V-39-eSE" else "images/sec whole-node ({} 3x800x1280)".format(args.body),
+                "value": round(total_images / elapsed, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "Full CenterMask2 {} (VoVNetV2-FPN + FCOS + CenterROIHeads/SAG-Mask/MaskIoU + ROIAlignV2), bs={} per GPU, "
+                                       "3x800x1280, end-to-end (BASELINE configs[3])".format(args.body, B),
+                           "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp{}".format(world),
+                           "launch": "hip-graph" if graph is not None else "eager",
+                           "collective": "RCCL all_gather of {} B/img records".format(rec.shape[1] * 4) if world > 1 else "none",
+                           "candidates_per_image": cand, "detections_per_image": dets,
+                           "weights": "seeded random-init, reference state-dict keys"},
+                "roofline": roof,
+            }
+            if cpu is not None:
+                result["cpu_baseline"] = cpu
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -247,6 +247,13 @@ class CenterROIHeads(HipModule):
         pooler_resolution = cfg.MODEL.ROI_MASK_HEAD.POOLER_RESOLUTION
         self.maskiou_head = build_maskiou_head(cfg, ShapeSpec(channels=in_channels, width=pooler_resolution, height=pooler_resolution))
 
+    def _img_area(self, image_sizes, dev):
+        key = (tuple(tuple(hw) for hw in image_sizes), str(dev))
+        cache = self.__dict__.setdefault("_img_area_cache", {})
+        if key not in cache:     # built once per size tuple: no H2D copy inside a captured graph
+            cache[key] = torch.tensor([float(hw[0] * hw[1]) for hw in image_sizes], dtype=torch.float32, device=dev)
+        return cache[key]
+
     # -- device-only core ----------------------------------------------------------------------------------------
     def forward_padded(self, features, det: dict, image_sizes, want=()) -> dict:
         """det: padded detections (box (N,K,4), score, cls int64, counts int32).  Adds pred_masks (N,K,1,28,28) and
@@ -262,7 +269,7 @@ class CenterROIHeads(HipModule):
         cpad = (c + 1 + 15) // 16 * 16
         s = pool.output_size
         roi = torch.empty((r, s, s, cpad), dtype=torch.float32, device=dev)
-        img_area = torch.tensor([float(hw[0] * hw[1]) for hw in image_sizes], dtype=torch.float32, device=dev)   # pooler.py:70-77
+        img_area = self._img_area(image_sizes, dev)                                                               # pooler.py:70-77
         levels = ops.roi_align_ratio(feats, pool.scales, det["box"], det["counts"], img_area, s, pool.sampling_ratio, roi, pool.min_level)
         dec = self.mask_head.features(View(roi, 0, c), det["counts"], k)
         P = self.mask_head.packed()

@@ -305,3 +305,31 @@ def mask_iou_score(iou: torch.Tensor, scores: torch.Tensor, cls: torch.Tensor) -
     check(lib.cmk_mask_iou_score(iou.data_ptr(), iou.shape[1], scores.data_ptr(), cls.data_ptr(), out.data_ptr(), r, _stream()),
           "cmk_mask_iou_score")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py's roofline leg): events on the launch stream around every conv
+# ---------------------------------------------------------------------------------------------------------------
+PROFILE = None       # when a list, conv2d appends (kernel_key, flops, algorithmic_bytes, start_event, end_event)
+
+_conv2d_plain = conv2d
+
+
+def conv2d(x, pc, y, **kw):  # noqa: F811
+    if PROFILE is None:
+        return _conv2d_plain(x, pc, y, **kw)
+    lib = _lib.load()
+    n, h, w = x.nhw
+    ho, wo = y.t.shape[1], y.t.shape[2]
+    taps = pc.k * pc.k
+    flops = 2.0 * n * ho * wo * pc.cin * pc.cout * taps
+    nbytes = 4.0 * (n * h * w * pc.cin + n * ho * wo * pc.cout + pc.cin * pc.cout * taps)
+    c32 = (pc.cout + 31) // 32
+    wn = c32 if c32 <= 7 else 4
+    wm = 1 if (pc.stride == 2 or wn > 4) else 2
+    key = "conv_igemm_kernel<{},{},{},{}>".format(taps, pc.stride, wm, wn)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _conv2d_plain(x, pc, y, **kw)
+    e1.record()
+    PROFILE.append((key, flops, nbytes, e0, e1, (n, h, w, pc.cin, pc.cout, pc.k, pc.stride)))

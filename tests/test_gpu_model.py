@@ -82,7 +82,7 @@ def test_end_to_end_800x1280_matches_reference(dev, model):
         assert len(inst) == r["scores"].shape[0]
         assert torch.equal(inst.pred_classes.cpu(), r["classes"]), "labels differ"
         assert torch.equal(inst.locations.cpu(), r["locations"]), "ROI locations differ"
-        close(inst.pred_boxes.tensor, r["boxes"], 1e-3 / 1280, "boxes")
+        close(inst.pred_boxes.tensor, r["boxes"], 2e-5, "boxes")   # pixels: reg (1e-3 bar, checked above) x stride x scale
         close(inst.scores, r["scores"], 1e-4, "scores")
         close(inst.pred_masks, r["pred_masks"], 1e-3, "pred_masks")
         close(inst.mask_scores, r["mask_scores"], 1e-3, "mask_scores")
