@@ -82,15 +82,30 @@ def roofline_leg(model, x, sizes):
     return roof
 
 
-def cpu_baseline_leg(sd, conv_body, budget_s=25.0):
-    """The oracle (plain PyTorch CPU ops + C nms/roi_align) on the same seeded workload, bounded to ~budget_s."""
-    from centermask2_amd import synthetic as S
-    from oracle import centermask_oracle as O
+def host_cores():
+    """Threads for the CPU leg: the cgroup CPU quota if there is one, else the affinity mask, capped at the 16-core
+    share a one-GPU box grants (CMK_CPU_THREADS overrides)."""
+    if os.environ.get("CMK_CPU_THREADS"):
+        return int(os.environ["CMK_CPU_THREADS"])
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(cores, 16)
+
+
+def cpu_baseline_leg(sd, conv_body, budget_s=25.0):
+    """The oracle (plain PyTorch CPU ops + C nms/roi_align) on the same seeded workload, bounded to ~budget_s."""
+    from centermask2_amd import synthetic as S
+    from oracle import centermask_oracle as O
+    cores = host_cores()
     torch.set_num_threads(cores)
     x = S.make_synthetic_images(1, 800, 1280, seed0=1234)
     t0 = time.time()
