@@ -43,11 +43,9 @@ def build(conv_body, device):
 
 
 def pack_results(out):
-    """Fixed-stride per-image record for the all-gather: 50 x (box4, score, mask_score, loc2, cls, mask784) + count."""
-    n, k = out["score"].shape
-    rec = torch.cat([out["box"].reshape(n, -1), out["score"], out["mask_scores"], out["loc"].reshape(n, -1),
-                     out["cls"].float(), out["pred_masks"].reshape(n, -1), out["counts"].float().reshape(n, 1)], dim=1)
-    return rec.contiguous()
+    """Fixed-stride per-image record for the all-gather (centermask2_amd/dist.py)."""
+    from centermask2_amd.dist import pack_records
+    return pack_records(out)
 
 
 def roofline_leg(model, x, sizes):

@@ -1,0 +1,175 @@
+"""not gpu: host logic — config, registries, structures, plugin construction, C-ABI export list, sharding + gloo gather."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from centermask2_amd import _lib
+    header = open(os.path.join(ROOT, "include", "cmk.h")).read()
+    declared = set(re.findall(r"\b(cmk_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                      # loads on CPU; no compute call is made here
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cmk_version() == 1 and lib.cmk_arch() == b"gfx950"
+    assert lib.cmk_conv_cout_pad(80) == 96 and lib.cmk_conv_cout_pad(160) == 160 and lib.cmk_conv_cout_pad(1024) == 1024
+    assert lib.cmk_conv_packed_floats(256, 257, 3) == 9 * 17 * 256 * 16
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Bad descriptors are rejected before any launch, with a message (error behaviour of the boundary)."""
+    from centermask2_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    assert lib.cmk_conv2d_nhwc(ctypes.byref(d), None) == -1 and b"null" in lib.cmk_last_error()
+    buf = (ctypes.c_float * 64)()
+    d.x = d.w = d.scale = d.shift = d.y = ctypes.addressof(buf)
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.x_cs, d.y_cs = 1, 2, 2, 24, 8, 3, 1, 24, 8
+    assert lib.cmk_conv2d_nhwc(ctypes.byref(d), None) == -1 and b"multiple of 16" in lib.cmk_last_error()
+    d.Cin, d.x_cs, d.ksize = 16, 16, 5
+    assert lib.cmk_conv2d_nhwc(ctypes.byref(d), None) == -1 and b"ksize" in lib.cmk_last_error()
+    assert lib.cmk_nms_topk(None, None, None, None, None, 1, 1, 0.6, 50, None, None, None, None, None, None, None, None) == -1
+
+
+def test_config_matches_reference_recipe():
+    from centermask2_amd.config import config_path, get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_file(config_path("centermask_V_39_eSE_FPN_ms_3x.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.FCOS.NMS_TH", 0.5])
+    cfg.freeze()
+    m = cfg.MODEL
+    assert m.BACKBONE.NAME == "build_fcos_vovnet_fpn_backbone" and m.PROPOSAL_GENERATOR.NAME == "FCOS" and m.ROI_HEADS.NAME == "CenterROIHeads"
+    assert m.ROI_MASK_HEAD.NAME == "SpatialAttentionMaskHead" and m.ROI_MASKIOU_HEAD.NAME == "MaskIoUHead"
+    assert m.FCOS.POST_NMS_TOPK_TEST == 50 and m.FCOS.INFERENCE_TH_TEST == 0.05 and m.FCOS.NMS_TH == 0.5
+    assert m.ROI_MASK_HEAD.ASSIGN_CRITERION == "ratio" and m.ROI_MASK_HEAD.POOLER_RESOLUTION == 14 and m.MASKIOU_ON and m.MASK_ON
+    assert m.VOVNET.CONV_BODY == "V-39-eSE" and m.VOVNET.OUT_FEATURES == ["stage3", "stage4", "stage5"]
+    with pytest.raises(AttributeError):
+        cfg.MODEL.DEVICE = "cuda"
+    with pytest.raises(KeyError):
+        get_cfg().merge_from_list(["MODEL.NOPE", 1])
+    c2 = cfg.clone()
+    c2.defrost()
+    c2.MODEL.DEVICE = "cuda"
+    assert cfg.MODEL.DEVICE == "cpu"
+
+
+def test_plugins_register_and_build_with_reference_keys():
+    from centermask2_amd import synthetic as S
+    from centermask2_amd.config import config_path, get_cfg
+    from centermask2_amd.modeling import build_model
+    from centermask2_amd.registry import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY,
+                                          ROI_MASK_HEAD_REGISTRY, ROI_MASKIOU_HEAD_REGISTRY)
+    for reg, name in ((BACKBONE_REGISTRY, "build_fcos_vovnet_fpn_backbone"), (BACKBONE_REGISTRY, "build_vovnet_backbone"),
+                      (PROPOSAL_GENERATOR_REGISTRY, "FCOS"), (ROI_HEADS_REGISTRY, "CenterROIHeads"), (META_ARCH_REGISTRY, "GeneralizedRCNN"),
+                      (ROI_MASK_HEAD_REGISTRY, "SpatialAttentionMaskHead"), (ROI_MASKIOU_HEAD_REGISTRY, "MaskIoUHead")):
+        assert name in reg and reg.get(name) is not None
+    for body, nkeys in (("V-39-eSE", 293), ("V-99-eSE", 613)):
+        cfg = get_cfg()
+        cfg.merge_from_file(config_path("centermask_V_39_eSE_FPN_ms_3x.yaml"))
+        cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.VOVNET.CONV_BODY", body])
+        model = build_model(cfg)
+        sd = model.state_dict()
+        shapes = S.model_param_shapes(body)
+        assert len(sd) == nkeys and set(sd) == set(shapes)
+        assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+    shp = model.backbone.output_shape()
+    assert list(shp) == ["p3", "p4", "p5", "p6", "p7"] and shp["p6"].stride == 64 and model.backbone.size_divisibility == 32
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from centermask2_amd._lib import CmkError
+    from centermask2_amd.config import config_path, get_cfg
+    from centermask2_amd.modeling import build_model
+    cfg = get_cfg()
+    cfg.merge_from_file(config_path("centermask_V_39_eSE_FPN_ms_3x.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu"])
+    model = build_model(cfg).eval()
+    with pytest.raises(CmkError):
+        model.backbone(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(CmkError):
+        model.proposal_generator.fcos_head([torch.zeros(1, 256, 8, 8)])
+
+
+def test_product_never_imports_oracle():
+    """The product package may mention the oracle in comments, but never imports, loads or links it."""
+    pat = re.compile(r"^\s*(import\s+oracle|from\s+oracle)|liboracle|oracle_ops\.so|oracle\._|CDLL\([^)]*oracle", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "centermask2_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".sh")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f
+
+
+def test_structures():
+    from centermask2_amd.structures import Boxes, FakeImageList, ImageList, Instances
+    b = Boxes(torch.tensor([[0., 0., 10., 20.], [5., 5., 5., 9.]]))
+    assert b.area().tolist() == [200.0, 0.0] and b.nonempty().tolist() == [True, False]
+    i = Instances((4, 6), pred_boxes=b, scores=torch.tensor([0.3, 0.7]))
+    j = i[torch.tensor([1])]
+    assert len(j) == 1 and j.scores.item() == pytest.approx(0.7) and j.image_size == (4, 6)
+    c = Instances.cat([i, i])
+    assert len(c) == 4 and c.pred_boxes.tensor.shape == (4, 4)
+    with pytest.raises(AssertionError):
+        i.bad = torch.zeros(3)
+    il = ImageList.from_tensors([torch.zeros(3, 5, 7), torch.zeros(3, 6, 4)], 32)
+    assert tuple(il.tensor.shape) == (2, 3, 32, 32) and il.image_sizes == [(5, 7), (6, 4)]
+    assert len(FakeImageList(torch.zeros(2, 3, 8, 8))) == 2 and FakeImageList(torch.zeros(1, 3, 8, 8)).image_sizes == [(1344, 1344)]
+
+
+def test_shard_ranges_cover_batch():
+    from centermask2_amd.dist import shard_range
+    for n in (1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def test_record_roundtrip():
+    from centermask2_amd.dist import pack_records, record_width, unpack_records
+    g = torch.Generator().manual_seed(0)
+    n, k = 3, 50
+    out = dict(box=torch.rand((n, k, 4), generator=g), score=torch.rand((n, k), generator=g), mask_scores=torch.rand((n, k), generator=g),
+               loc=torch.rand((n, k, 2), generator=g), cls=torch.randint(0, 80, (n, k), generator=g),
+               pred_masks=torch.rand((n, k, 1, 28, 28), generator=g), counts=torch.tensor([50, 0, 17], dtype=torch.int32))
+    rec = pack_records(out)
+    assert rec.shape == (n, record_width(k))
+    back = unpack_records(rec, k)
+    for key in out:
+        assert torch.equal(back[key], out[key]), key
+
+
+_GLOO_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from centermask2_amd.dist import all_gather_records, shard_range
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n_images, width = 5, 11
+full = torch.arange(n_images * width, dtype=torch.float32).reshape(n_images, width)
+lo, hi = shard_range(n_images, rank, world)
+per_rank = -(-n_images // world)
+got = all_gather_records(full[lo:hi].clone(), per_rank, n_images)
+assert torch.equal(got, full), (rank, got)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_all_gather_world_size_2_gloo(tmp_path):
+    """The N>1 path (uneven shards, zero-padded all-gather) with two CPU processes over gloo."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
