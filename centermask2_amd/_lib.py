@@ -35,6 +35,7 @@ SIGNATURES = {
     "cmk_arch": (c_char_p, []),
     "cmk_last_error": (c_char_p, []),
     "cmk_conv2d_nhwc": (c_int, [POINTER(ConvDesc), c_void_p]),
+    "cmk_conv2d_nhwc_multi": (c_int, [POINTER(ConvDesc), c_int, c_void_p]),
     "cmk_conv_packed_floats": (c_int64, [c_int, c_int, c_int]),
     "cmk_conv_cout_pad": (c_int, [c_int]),
     "cmk_stem_conv_nchw3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

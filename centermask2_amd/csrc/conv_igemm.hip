@@ -6,9 +6,10 @@
 //   per-FMA register traffic.  A 32x32 accumulator's column sits on the lane, so Cout is mapped to the lane
 //   (128-byte contiguous NHWC stores) and pixels to the accumulator rows.
 //
-//   Tiling (block = 4 waves stacked along M):
-//     3x3:  spatial tile of (8*WM) x 16 output pixels; its input halo tile is staged ONCE per 16-channel K chunk
-//           in LDS and the 9 taps read it at shifted addresses (9x fewer global->LDS bytes than per-tap im2col).
+//   Tiling (block = 4 waves stacked along M, wave tile = WM x WN accumulators of 32 pixels x 32 couts):
+//     3x3:  spatial tile of (4*WM*SR) x SC output pixels, a wave sub-tile being SR x SC = 2x16 or 1x32 pixels; the
+//           input halo tile is staged ONCE per 16-channel K chunk in LDS and the 9 taps read it at shifted addresses
+//           (9x fewer global->LDS bytes than per-tap im2col).
 //     1x1:  128*WM consecutive pixels of the flattened (N*H*W) axis.
 //     Per K chunk and tap the block stages a [32*WN couts][16 ci] weight slab (pre-packed, contiguous in HBM).
 //   K order inside a 16-chunk is permuted so that MFMA k-step s of lane half h uses channel 8h+s: every lane then
@@ -16,9 +17,17 @@
 //   (80 B), which spreads the 16-lane ds_read_b128 groups over all 16-byte LDS slots.
 //   Pipeline: global loads for step s+1 (weights) and chunk c+1 (halo) are issued before the barrier of step s
 //   and written to the other LDS buffer after its MFMAs (register-staged double buffering, one barrier per step).
+//   Staging loads are branch-free (clamped address, zero selected at the LDS write) so the compiler keeps them in
+//   flight across the MFMA block.
+//   Scheduling: the matrix pipe is the bound, so what matters is that every CU holds the same number of equally long
+//   workgroups.  The host picks (WM, sub-tile shape) per layer from a small menu with a residency/round cost model
+//   (choose_variant), and layers that share weights across FPN levels (FCOS towers/predictors) run as ONE launch
+//   whose block index walks the tiles of all levels.
 //
 // Reference call sites replaced: aten::conv2d + FrozenBN + ReLU vovnet.py:205-236; d2 FPN convs (vovnet.py:547-554);
 // fpn.py:27-35; fcos.py:169-200; sam.py:58-83; maskiou_head.py:81-93; nn.Linear maskiou_head.py:89-91.
+#include <stdlib.h>
+
 #include "cmk_common.hpp"
 
 namespace cmk {
@@ -26,38 +35,54 @@ namespace cmk {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PST = 20;  // LDS row pitch in floats: 16 channels + 4 pad
+constexpr int PST = 20;      // LDS row pitch in floats: 16 channels + 4 pad
+constexpr int MAXP = 5;      // problems (FPN levels) per launch
+constexpr int LDS_CU = 160 * 1024;
 
-struct ConvArgs {
-    const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
-    int N, H, W, Ho, Wo, Cin, Cout;
-    int x_cs, x_co, y_cs, y_co, res_cs, res_co, res_mode, Hr, Wr;
-    int relu_upto, in_relu;
-    int tiles_h, tiles_w, cout_pad;
+// workgroups per CU the register budget allows (accumulators: 16 VGPRs per 32x32 tile)
+__host__ __device__ constexpr int occ_of(int wm, int wn, int stride) { return (stride == 1 && (wm == 1 ? wn <= 5 : wn <= 2)) ? 3 : 2; }
+
+struct ConvProblem {
+    const float* x; float* y; const float* scale; const float* shift;
+    int N, H, W, Ho, Wo;
+    int tiles_h, tiles_w, tile_begin;
     long total_pix;  // N*Ho*Wo
 };
 
-template <int TAPS, int STRIDE, int WM, int WN>
+struct ConvArgs {
+    ConvProblem p[MAXP];
+    int nprob;
+    const float* w; const float* res;
+    int Cin, Cout;
+    int x_cs, x_co, y_cs, y_co, res_cs, res_co, res_mode, Hr, Wr;
+    int relu_upto, in_relu;
+    int cout_pad;
+};
+
+template <int TAPS, int STRIDE, int WM, int WN, int SC>
 struct Geo {
+    static constexpr int SR = 32 / SC;   // sub-tile rows
     static constexpr int SUBT = 4 * WM;  // 32-pixel sub-tiles per block
     static constexpr int BM = 32 * SUBT;
     static constexpr int BN = 32 * WN;
-    static constexpr int TH = (TAPS == 9) ? 2 * SUBT : 1;
-    static constexpr int TW = (TAPS == 9) ? 16 : BM;
+    static constexpr int TH = (TAPS == 9) ? SR * SUBT : 1;
+    static constexpr int TW = (TAPS == 9) ? SC : BM;
     static constexpr int HH = (TAPS == 9) ? (TH - 1) * STRIDE + 3 : 1;
     static constexpr int HWD = (TAPS == 9) ? (TW - 1) * STRIDE + 3 : BM;
     static constexpr int APIX = HH * HWD;
     static constexpr int A_BYTES = APIX * PST * 4;
     static constexpr int B_BYTES = BN * PST * 4;
-    static constexpr bool ADB = (2 * A_BYTES + 2 * B_BYTES) <= 80 * 1024;  // double-buffer the halo if 2 blocks/CU still fit
+    static constexpr int OCC = occ_of(WM, WN, STRIDE);
+    static constexpr bool ADB = (2 * A_BYTES + 2 * B_BYTES) * OCC <= LDS_CU;   // double-buffer the halo only if residency is kept
     static constexpr int LDS_BYTES = (ADB ? 2 : 1) * A_BYTES + 2 * B_BYTES;
+    static constexpr int RESIDENT = (LDS_BYTES * OCC <= LDS_CU) ? OCC : (LDS_BYTES * 2 <= LDS_CU ? 2 : 1);
     static constexpr int A_ITERS = (APIX * 4 + 255) / 256;
     static constexpr int B_ITERS = (BN * 4 + 255) / 256;
 };
 
-template <int TAPS, int STRIDE, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
-    using G = Geo<TAPS, STRIDE, WM, WN>;
+template <int TAPS, int STRIDE, int WM, int WN, int SC>
+__global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kernel(const ConvArgs a) {
+    using G = Geo<TAPS, STRIDE, WM, WN, SC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sB = smem + (G::ADB ? 2 : 1) * G::APIX * PST;
@@ -68,75 +93,84 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const int hh = lane >> 5;  // k half
     const int li = lane & 31;
 
+    // ---- which problem (FPN level) and which tile ------------------------------------------------------------
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < a.nprob && (int)blockIdx.x >= a.p[i].tile_begin) pi = i;
+    const ConvProblem& P = a.p[pi];
+    const int H = P.H, W = P.W, Ho = P.Ho, Wo = P.Wo;
+    const long total_pix = P.total_pix;
+    const int tile = blockIdx.x - P.tile_begin;
     int n = 0, oh0 = 0, ow0 = 0;
     long pix0 = 0;
     if (TAPS == 9) {
-        int tile = blockIdx.x;
-        int tw = tile % p.tiles_w;
-        int t2 = tile / p.tiles_w;
-        int th = t2 % p.tiles_h;
-        n = t2 / p.tiles_h;
+        int tw = tile % P.tiles_w;
+        int t2 = tile / P.tiles_w;
+        int th = t2 % P.tiles_h;
+        n = t2 / P.tiles_h;
         oh0 = th * G::TH;
         ow0 = tw * G::TW;
     } else {
-        pix0 = (long)blockIdx.x * G::BM;
+        pix0 = (long)tile * G::BM;
     }
     const int co0 = blockIdx.y * G::BN;
-    const int nchunks = p.Cin >> 4;
+    const int nchunks = a.Cin >> 4;
     const int total_steps = nchunks * TAPS;
 
-    // ---- per-thread staging descriptors ------------------------------------------------------------------
-    const float* xin = p.x + (TAPS == 9 ? (long)n * p.H * p.W * p.x_cs : 0L) + p.x_co;
-    long a_goff[G::A_ITERS];
-    int a_loff[G::A_ITERS];
+    // ---- per-thread staging descriptors ------------------------------------------------------------------------
+    const float* xin = P.x + (TAPS == 9 ? (long)n * H * W * a.x_cs : 0L) + a.x_co;
+    long a_goff[G::A_ITERS];   // clamped to a valid address; a_ok tells whether the value is used
+    unsigned a_ok = 0;
 #pragma unroll
     for (int it = 0; it < G::A_ITERS; ++it) {
         int idx = it * 256 + tid;
         int pix = idx >> 2, q = idx & 3;
-        a_loff[it] = pix * PST + q * 4;
-        a_goff[it] = -1;
+        long off = 0;
         if (idx < G::APIX * 4) {
             if (TAPS == 9) {
                 int hr = pix / G::HWD, hc = pix - hr * G::HWD;
                 int ih = oh0 * STRIDE - 1 + hr, iw = ow0 * STRIDE - 1 + hc;
-                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) a_goff[it] = ((long)ih * p.W + iw) * p.x_cs + q * 4;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) { off = ((long)ih * W + iw) * a.x_cs + q * 4; a_ok |= 1u << it; }
             } else {
-                long P = pix0 + pix;
-                if (P < p.total_pix) a_goff[it] = P * p.x_cs + q * 4;
+                long Pp = pix0 + pix;
+                if (Pp < total_pix) { off = Pp * a.x_cs + q * 4; a_ok |= 1u << it; }
             }
-        } else {
-            a_loff[it] = -1;
         }
+        a_goff[it] = off;
     }
     f32x4 a_stage[G::A_ITERS];
     f32x4 b_stage[G::B_ITERS];
 
     auto load_A = [&](int chunk) {
 #pragma unroll
-        for (int it = 0; it < G::A_ITERS; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_goff[it] >= 0) v = *reinterpret_cast<const f32x4*>(xin + a_goff[it] + chunk * 16);
-            a_stage[it] = v;
-        }
+        for (int it = 0; it < G::A_ITERS; ++it) a_stage[it] = *reinterpret_cast<const f32x4*>(xin + a_goff[it] + chunk * 16);
     };
     auto store_A = [&](int buf) {
         float* dst = sA + buf * (G::APIX * PST);
 #pragma unroll
         for (int it = 0; it < G::A_ITERS; ++it) {
-            if (a_loff[it] >= 0) {
+            int idx = it * 256 + tid;
+            if ((it + 1) * 256 <= G::APIX * 4 || idx < G::APIX * 4) {
                 f32x4 v = a_stage[it];
-                if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<f32x4*>(dst + a_loff[it]) = v;
+                const bool ok = (a_ok >> it) & 1u;
+                if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                v.x = ok ? v.x : 0.f;
+                v.y = ok ? v.y : 0.f;
+                v.z = ok ? v.z : 0.f;
+                v.w = ok ? v.w : 0.f;
+                *reinterpret_cast<f32x4*>(dst + (idx >> 2) * PST + (idx & 3) * 4) = v;
             }
         }
     };
     auto load_B = [&](int step) {
         int chunk = step / TAPS, tap = step - chunk * TAPS;
-        const float* wsrc = p.w + ((long)(tap * nchunks + chunk) * p.cout_pad + co0) * 16;
+        const float* wsrc = a.w + ((long)(tap * nchunks + chunk) * a.cout_pad + co0) * 16;
 #pragma unroll
         for (int it = 0; it < G::B_ITERS; ++it) {
             int idx = it * 256 + tid;
-            if (idx < G::BN * 4) b_stage[it] = *reinterpret_cast<const f32x4*>(wsrc + idx * 4);
+            if ((it + 1) * 256 > G::BN * 4) idx = min(idx, G::BN * 4 - 1);   // ragged last iteration: clamp, do not branch
+            b_stage[it] = *reinterpret_cast<const f32x4*>(wsrc + idx * 4);
         }
     };
     auto store_B = [&](int buf) {
@@ -144,18 +178,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int it = 0; it < G::B_ITERS; ++it) {
             int idx = it * 256 + tid;
-            if (idx < G::BN * 4) *reinterpret_cast<f32x4*>(dst + (idx >> 2) * PST + (idx & 3) * 4) = b_stage[it];
+            if ((it + 1) * 256 <= G::BN * 4 || idx < G::BN * 4)
+                *reinterpret_cast<f32x4*>(dst + (idx >> 2) * PST + (idx & 3) * 4) = b_stage[it];
         }
     };
 
-    // ---- MFMA operand addresses -----------------------------------------------------------------------------
+    // ---- MFMA operand addresses -----------------------------------------------------------------------------------
     int a_off[WM];
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         int u = wave * WM + m;
         if (TAPS == 9) {
-            int r = li >> 4, cc = li & 15;
-            a_off[m] = (((u * 2 + r) * STRIDE) * G::HWD + cc * STRIDE) * PST + hh * 8;
+            int r = li / SC, cc = li % SC;
+            a_off[m] = (((u * G::SR + r) * STRIDE) * G::HWD + cc * STRIDE) * PST + hh * 8;
         } else {
             a_off[m] = (u * 32 + li) * PST + hh * 8;
         }
@@ -170,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
 
-    // ---- prologue ---------------------------------------------------------------------------------------------
+    // ---- prologue ---------------------------------------------------------------------------------------------------
     load_A(0);
     load_B(0);
     store_A(0);
@@ -223,14 +258,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         }
     }
 
-    // ---- epilogue: scale/shift (+residual) (+ReLU), NHWC store -------------------------------------------------
+    // ---- epilogue: scale/shift (+residual) (+ReLU), NHWC store -------------------------------------------------------
 #pragma unroll
     for (int nn = 0; nn < WN; ++nn) {
         const int co = co0 + nn * 32 + li;
-        const bool cvalid = co < p.Cout;
-        const float sc = cvalid ? p.scale[co] : 0.f;
-        const float sh = cvalid ? p.shift[co] : 0.f;
-        const bool do_relu = co < p.relu_upto;
+        const bool cvalid = co < a.Cout;
+        const float sc = cvalid ? P.scale[co] : 0.f;
+        const float sh = cvalid ? P.shift[co] : 0.f;
+        const bool do_relu = co < a.relu_upto;
 #pragma unroll
         for (int m = 0; m < WM; ++m) {
             const int u = wave * WM + m;
@@ -241,80 +276,189 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
                 bool pvalid;
                 int oh = 0, ow = 0;
                 if (TAPS == 9) {
-                    oh = oh0 + u * 2 + (row >> 4);
-                    ow = ow0 + (row & 15);
-                    pvalid = (oh < p.Ho) && (ow < p.Wo);
-                    opix = ((long)n * p.Ho + oh) * p.Wo + ow;
+                    oh = oh0 + u * G::SR + row / SC;
+                    ow = ow0 + row % SC;
+                    pvalid = (oh < Ho) && (ow < Wo);
+                    opix = ((long)n * Ho + oh) * Wo + ow;
                 } else {
                     opix = pix0 + u * 32 + row;
-                    pvalid = opix < p.total_pix;
+                    pvalid = opix < total_pix;
                 }
                 if (cvalid && pvalid) {
                     float v = acc[m][nn][r] * sc + sh;
-                    if (p.res_mode == 1) {
-                        v += p.res[opix * p.res_cs + p.res_co + co];
-                    } else if (p.res_mode == 2) {
+                    if (a.res_mode == 1) {
+                        v += a.res[opix * a.res_cs + a.res_co + co];
+                    } else if (a.res_mode == 2) {
+                        int nn_ = n;
                         if (TAPS != 9) {  // recover (n, oh, ow) from the flattened pixel index
-                            long hw = (long)p.Ho * p.Wo;
-                            n = (int)(opix / hw);
-                            int rem = (int)(opix - (long)n * hw);
-                            oh = rem / p.Wo;
-                            ow = rem - oh * p.Wo;
+                            long hw = (long)Ho * Wo;
+                            nn_ = (int)(opix / hw);
+                            int rem = (int)(opix - (long)nn_ * hw);
+                            oh = rem / Wo;
+                            ow = rem - oh * Wo;
                         }
-                        long rp = ((long)n * p.Hr + (oh >> 1)) * p.Wr + (ow >> 1);
-                        v += p.res[rp * p.res_cs + p.res_co + co];
+                        long rp = ((long)nn_ * a.Hr + (oh >> 1)) * a.Wr + (ow >> 1);
+                        v += a.res[rp * a.res_cs + a.res_co + co];
                     }
                     if (do_relu) v = fmaxf(v, 0.f);
-                    p.y[opix * p.y_cs + p.y_co + co] = v;
+                    P.y[opix * a.y_cs + a.y_co + co] = v;
                 }
             }
         }
     }
 }
 
-template <int TAPS, int STRIDE, int WM, int WN>
-static int launch(const ConvArgs& a, int grid_x, int grid_y, hipStream_t st) {
-    using G = Geo<TAPS, STRIDE, WM, WN>;
+// ---------------------------------------------------------------------------------------------------------------
+// host side: variant menu + cost model
+// ---------------------------------------------------------------------------------------------------------------
+struct Variant { int wm, sc; };
+
+template <int TAPS, int STRIDE, int WM, int WN, int SC>
+static int launch(ConvArgs& a, int grid_y, hipStream_t st) {
+    using G = Geo<TAPS, STRIDE, WM, WN, SC>;
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<TAPS, STRIDE, WM, WN>;
+    auto kern = conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            G::LDS_BYTES);
         if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid_x, grid_y), dim3(256), G::LDS_BYTES, st, a);
+    int blocks = 0;
+    for (int i = 0; i < a.nprob; ++i) {
+        ConvProblem& p = a.p[i];
+        p.tile_begin = blocks;
+        if (TAPS == 9) {
+            p.tiles_h = cdiv(p.Ho, G::TH);
+            p.tiles_w = cdiv(p.Wo, G::TW);
+            blocks += p.N * p.tiles_h * p.tiles_w;
+        } else {
+            p.tiles_h = p.tiles_w = 0;
+            blocks += (int)((p.total_pix + G::BM - 1) / G::BM);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks, grid_y), dim3(256), G::LDS_BYTES, st, a);
     return check_launch("conv_igemm");
 }
 
+// cost of running `blocks` equal workgroups of BM pixels with `resident` per CU on 256 CUs: full rounds keep every CU at
+// `resident` workgroups; the last round spreads round-robin.  eff(j) = matrix-pipe utilisation with j workgroups on a CU.
+static double round_cost(long blocks, int resident, int bm) {
+    static const double eff[4] = {1.0, 0.70, 0.90, 0.95};
+    const long slots = 256L * resident;
+    long full = blocks / slots, rem = blocks % slots;
+    double c = (double)full * resident * bm / eff[resident];
+    if (rem) {
+        int j = (int)((rem + 255) / 256);
+        c += (double)j * bm / eff[j];
+    }
+    return c;
+}
+
+template <int TAPS, int STRIDE, int WN>
+static Variant choose_variant(const ConvArgs& a, int grid_y) {
+    static const char* force = getenv("CMK_CONV_VARIANT");   // e.g. "2x16", "1x32" (debug / tuning)
+    Variant best{1, 16};
+    double best_cost = 1e300;
+    for (int wm = 2; wm >= 1; --wm) {
+        if (wm == 2 && (WN > 4 || STRIDE == 2)) continue;
+        for (int sc = 16; sc <= 32; sc += 16) {
+            if (TAPS == 1 && sc == 16) continue;          // 1x1 has no spatial tile shape
+            if (STRIDE == 2 && sc == 32) continue;        // halo of a 4x32 stride-2 tile does not pay
+            if (force && (force[0] - '0' != wm || atoi(force + 2) != sc) && !(TAPS == 1 && force[0] - '0' == wm)) continue;
+            const int sr = 32 / sc, bm = 128 * wm;
+            const int th = TAPS == 9 ? sr * 4 * wm : 1, tw = TAPS == 9 ? sc : bm;
+            long blocks = 0;
+            for (int i = 0; i < a.nprob; ++i)
+                blocks += TAPS == 9 ? (long)a.p[i].N * cdiv(a.p[i].Ho, th) * cdiv(a.p[i].Wo, tw) : (a.p[i].total_pix + bm - 1) / bm;
+            blocks *= grid_y;
+            // residency as Geo computes it
+            const int apix = TAPS == 9 ? ((th - 1) * STRIDE + 3) * ((tw - 1) * STRIDE + 3) : bm;
+            const int abytes = apix * PST * 4, bbytes = 32 * WN * PST * 4;
+            const int occ = occ_of(wm, WN, STRIDE);
+            const bool adb = (2 * abytes + 2 * bbytes) * occ <= LDS_CU;
+            const int lds = (adb ? 2 : 1) * abytes + 2 * bbytes;
+            const int resident = lds * occ <= LDS_CU ? occ : (lds * 2 <= LDS_CU ? 2 : 1);
+            double cost = round_cost(blocks, resident, bm) * (wm == 1 ? 1.03 : 1.0);
+            if (cost < best_cost) { best_cost = cost; best = Variant{wm, sc}; }
+        }
+    }
+    return best;
+}
+
+template <int TAPS, int STRIDE, int WN>
+static int dispatch_variant(ConvArgs& a, int grid_y, hipStream_t st) {
+    Variant v = choose_variant<TAPS, STRIDE, WN>(a, grid_y);
+    if constexpr (TAPS == 1) {
+        if constexpr (WN <= 4) { if (v.wm == 2) return launch<1, 1, 2, WN, 32>(a, grid_y, st); }
+        return launch<1, 1, 1, WN, 32>(a, grid_y, st);
+    } else if constexpr (STRIDE == 2) {
+        return launch<9, 2, 1, WN, 16>(a, grid_y, st);
+    } else {
+        if constexpr (WN <= 4) {
+            if (v.wm == 2) return v.sc == 16 ? launch<9, 1, 2, WN, 16>(a, grid_y, st) : launch<9, 1, 2, WN, 32>(a, grid_y, st);
+        }
+        return v.sc == 16 ? launch<9, 1, 1, WN, 16>(a, grid_y, st) : launch<9, 1, 1, WN, 32>(a, grid_y, st);
+    }
+}
+
 template <int TAPS, int STRIDE>
-static int dispatch_wn(const ConvArgs& a0, int cout32, hipStream_t st) {
-    ConvArgs a = a0;
-    // WN<=4: WM=2 (except stride 2, whose halo only fits with WM=1); 5..7: WM=1; >=8: 128-wide N tiles.
-    constexpr int WMs = (STRIDE == 2) ? 1 : 2;
+static int dispatch_wn(ConvArgs& a, int cout32, hipStream_t st) {
     int wn = cout32 <= 7 ? cout32 : 4;
     int grid_y = cout32 <= 7 ? 1 : cdiv(cout32, 4);
     a.cout_pad = grid_y * wn * 32;
-    int wm = (wn <= 4) ? WMs : 1;
-    int grid_x;
-    if (TAPS == 9) {
-        int th = 8 * wm;
-        a.tiles_h = cdiv(a.Ho, th);
-        a.tiles_w = cdiv(a.Wo, 16);
-        grid_x = a.N * a.tiles_h * a.tiles_w;
-    } else {
-        grid_x = (int)((a.total_pix + 128 * wm - 1) / (128 * wm));
-    }
     switch (wn) {
-        case 1: return launch<TAPS, STRIDE, WMs, 1>(a, grid_x, grid_y, st);
-        case 2: return launch<TAPS, STRIDE, WMs, 2>(a, grid_x, grid_y, st);
-        case 3: return launch<TAPS, STRIDE, WMs, 3>(a, grid_x, grid_y, st);
-        case 4: return launch<TAPS, STRIDE, WMs, 4>(a, grid_x, grid_y, st);
-        case 5: return launch<TAPS, STRIDE, 1, 5>(a, grid_x, grid_y, st);
-        case 6: return launch<TAPS, STRIDE, 1, 6>(a, grid_x, grid_y, st);
-        case 7: return launch<TAPS, STRIDE, 1, 7>(a, grid_x, grid_y, st);
+        case 1: return dispatch_variant<TAPS, STRIDE, 1>(a, grid_y, st);
+        case 2: return dispatch_variant<TAPS, STRIDE, 2>(a, grid_y, st);
+        case 3: return dispatch_variant<TAPS, STRIDE, 3>(a, grid_y, st);
+        case 4: return dispatch_variant<TAPS, STRIDE, 4>(a, grid_y, st);
+        case 5: return dispatch_variant<TAPS, STRIDE, 5>(a, grid_y, st);
+        case 6: return dispatch_variant<TAPS, STRIDE, 6>(a, grid_y, st);
+        case 7: return dispatch_variant<TAPS, STRIDE, 7>(a, grid_y, st);
     }
     return fail(CMK_EINVAL, "conv: bad WN%s", "");
+}
+
+static int validate(const cmk_conv_desc* d) {
+    if (!d || !d->x || !d->w || !d->y || !d->scale || !d->shift) return fail(CMK_EINVAL, "conv: null pointer%s", "");
+    if (d->ksize != 1 && d->ksize != 3) return fail(CMK_EINVAL, "conv: ksize must be 1 or 3%s", "");
+    if (d->stride != 1 && d->stride != 2) return fail(CMK_EINVAL, "conv: stride must be 1 or 2%s", "");
+    if (d->ksize == 1 && d->stride != 1) return fail(CMK_EINVAL, "conv: 1x1 stride 2 unsupported%s", "");
+    if (d->Cin <= 0 || (d->Cin & 15)) return fail(CMK_EINVAL, "conv: Cin (%s%ld) must be a positive multiple of 16", "", d->Cin);
+    if (d->Cout <= 0 || d->N <= 0 || d->H <= 0 || d->W <= 0) return fail(CMK_EINVAL, "conv: empty shape%s", "");
+    if ((d->x_cs & 3) || (d->x_co & 3)) return fail(CMK_EINVAL, "conv: input view must be 16-byte aligned per pixel%s", "");
+    if (((uintptr_t)d->x & 15) || ((uintptr_t)d->w & 15)) return fail(CMK_EINVAL, "conv: x/w must be 16-byte aligned%s", "");
+    if (d->x_co + d->Cin > d->x_cs || d->y_co + d->Cout > d->y_cs) return fail(CMK_EINVAL, "conv: channel view out of range%s", "");
+    if (d->res_mode < 0 || d->res_mode > 2 || (d->res_mode && !d->res)) return fail(CMK_EINVAL, "conv: bad residual%s", "");
+    return CMK_OK;
+}
+
+static void fill_problem(ConvProblem& p, const cmk_conv_desc* d) {
+    p.x = d->x; p.y = d->y; p.scale = d->scale; p.shift = d->shift;
+    p.N = d->N; p.H = d->H; p.W = d->W;
+    p.Ho = d->stride == 1 ? d->H : (d->H - 1) / 2 + 1;  // k3 p1 s2: floor((H+2-3)/2)+1
+    p.Wo = d->stride == 1 ? d->W : (d->W - 1) / 2 + 1;
+    p.tiles_h = p.tiles_w = p.tile_begin = 0;
+    p.total_pix = (long)p.N * p.Ho * p.Wo;
+}
+
+static int run(const cmk_conv_desc* descs, int n, void* stream) {
+    const cmk_conv_desc* d = &descs[0];
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nprob = n;
+    for (int i = 0; i < n; ++i) fill_problem(a.p[i], &descs[i]);
+    a.w = d->w; a.res = d->res;
+    a.Cin = d->Cin; a.Cout = d->Cout;
+    a.x_cs = d->x_cs; a.x_co = d->x_co; a.y_cs = d->y_cs; a.y_co = d->y_co;
+    a.res_cs = d->res_cs; a.res_co = d->res_co; a.res_mode = d->res_mode; a.Hr = d->Hr; a.Wr = d->Wr;
+    if (a.res_mode == 2 && (a.Hr * 2 < a.p[0].Ho || a.Wr * 2 < a.p[0].Wo)) return fail(CMK_EINVAL, "conv: upsampled residual too small%s", "");
+    a.relu_upto = d->relu_upto; a.in_relu = d->in_relu;
+    const int cout32 = (d->Cout + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->ksize == 1) return dispatch_wn<1, 1>(a, cout32, st);
+    if (d->stride == 1) return dispatch_wn<9, 1>(a, cout32, st);
+    return dispatch_wn<9, 2>(a, cout32, st);
 }
 
 }  // namespace cmk
@@ -331,31 +475,22 @@ extern "C" int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize) {
 }
 
 extern "C" int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream) {
+    int rc = cmk::validate(d);
+    if (rc) return rc;
+    return cmk::run(d, 1, stream);
+}
+
+extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* stream) {
     using namespace cmk;
-    if (!d || !d->x || !d->w || !d->y || !d->scale || !d->shift) return fail(CMK_EINVAL, "conv: null pointer%s", "");
-    if (d->ksize != 1 && d->ksize != 3) return fail(CMK_EINVAL, "conv: ksize must be 1 or 3%s", "");
-    if (d->stride != 1 && d->stride != 2) return fail(CMK_EINVAL, "conv: stride must be 1 or 2%s", "");
-    if (d->ksize == 1 && d->stride != 1) return fail(CMK_EINVAL, "conv: 1x1 stride 2 unsupported%s", "");
-    if (d->Cin <= 0 || (d->Cin & 15)) return fail(CMK_EINVAL, "conv: Cin (%s%ld) must be a positive multiple of 16", "", d->Cin);
-    if (d->Cout <= 0 || d->N <= 0 || d->H <= 0 || d->W <= 0) return fail(CMK_EINVAL, "conv: empty shape%s", "");
-    if ((d->x_cs & 3) || (d->x_co & 3)) return fail(CMK_EINVAL, "conv: input view must be 16-byte aligned per pixel%s", "");
-    if (((uintptr_t)d->x & 15) || ((uintptr_t)d->w & 15)) return fail(CMK_EINVAL, "conv: x/w must be 16-byte aligned%s", "");
-    if (d->x_co + d->Cin > d->x_cs || d->y_co + d->Cout > d->y_cs) return fail(CMK_EINVAL, "conv: channel view out of range%s", "");
-    if (d->res_mode < 0 || d->res_mode > 2 || (d->res_mode && !d->res)) return fail(CMK_EINVAL, "conv: bad residual%s", "");
-    ConvArgs a;
-    a.x = d->x; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.y = d->y;
-    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
-    a.Ho = d->stride == 1 ? d->H : (d->H - 1) / 2 + 1;  // k3 p1 s2: floor((H+2-3)/2)+1
-    a.Wo = d->stride == 1 ? d->W : (d->W - 1) / 2 + 1;
-    a.x_cs = d->x_cs; a.x_co = d->x_co; a.y_cs = d->y_cs; a.y_co = d->y_co;
-    a.res_cs = d->res_cs; a.res_co = d->res_co; a.res_mode = d->res_mode; a.Hr = d->Hr; a.Wr = d->Wr;
-    if (a.res_mode == 2 && (a.Hr * 2 < a.Ho || a.Wr * 2 < a.Wo)) return fail(CMK_EINVAL, "conv: upsampled residual too small%s", "");
-    a.relu_upto = d->relu_upto; a.in_relu = d->in_relu;
-    a.tiles_h = a.tiles_w = 0; a.cout_pad = 0;
-    a.total_pix = (long)a.N * a.Ho * a.Wo;
-    const int cout32 = (d->Cout + 31) / 32;
-    hipStream_t st = (hipStream_t)stream;
-    if (d->ksize == 1) return dispatch_wn<1, 1>(a, cout32, st);
-    if (d->stride == 1) return dispatch_wn<9, 1>(a, cout32, st);
-    return dispatch_wn<9, 2>(a, cout32, st);
+    if (!descs || n < 1 || n > MAXP) return fail(CMK_EINVAL, "conv_multi: need 1..%s%ld problems", "", MAXP);
+    for (int i = 0; i < n; ++i) {
+        int rc = validate(&descs[i]);
+        if (rc) return rc;
+        const cmk_conv_desc *a = &descs[0], *b = &descs[i];
+        if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
+            b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
+            b->y_co != a->y_co || b->res_mode != 0)
+            return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
+    }
+    return run(descs, n, stream);
 }

@@ -101,26 +101,29 @@ class FCOSHead(HipModule):
         return P
 
     @staticmethod
-    def _run_tower(x: View, tower) -> View:
+    def _run_tower(xs: List[View], tower) -> List[View]:
+        """One launch per tower conv over ALL levels (the weights are shared, fcos.py:227-231), then GN+ReLU per level."""
         for pc, gamma, beta, eps, groups in tower:
             if gamma is None:
-                x = ops.conv_out(x, pc, relu=True)
+                xs = ops.conv_out_multi(xs, [pc] * len(xs), relu=True)
             else:
-                x = ops.conv_out(x, pc)
-                ops.groupnorm_relu_(x.t, gamma, beta, groups, eps)
-        return x
+                xs = ops.conv_out_multi(xs, [pc] * len(xs))
+                for x in xs:
+                    ops.groupnorm_relu_(x.t, gamma, beta, groups, eps)
+        return xs
 
     def forward_views(self, feats: List[View]):
         """-> (logits[l] (N,H,W,C) NHWC, regctr[l] (N,H,W,5) = [relu(scale_l*bbox_pred) x4, ctrness logit])."""
         P = self.packed()
-        logits, regctr = [], []
-        for l, f in enumerate(feats):
-            f = self._run_tower(f, P["share"])
+        nl = len(feats)
+        out_l, out_r = [], []
+        for g0 in range(0, nl, 5):                      # the multi-problem launch takes up to 5 levels
+            f = self._run_tower(list(feats[g0:g0 + 5]), P["share"])
             cls_t = self._run_tower(f, P["cls"])
             box_t = self._run_tower(f, P["bbox"])
-            logits.append(ops.conv_out(cls_t, P["cls_logits"]).t)
-            regctr.append(ops.conv_out(box_t, P["regctr"][l], relu_upto=4).t)       # fcos.py:233-238
-        return logits, regctr
+            out_l += [v.t for v in ops.conv_out_multi(cls_t, [P["cls_logits"]] * len(cls_t))]
+            out_r += [v.t for v in ops.conv_out_multi(box_t, P["regctr"][g0:g0 + 5], relu_upto=4)]       # fcos.py:233-238
+        return out_l, out_r
 
     def forward(self, x: List[torch.Tensor]):
         """Reference signature (fcos.py:222-240): NCHW logits, bbox_reg, ctrness, bbox_towers([])."""

@@ -97,12 +97,9 @@ def fold_frozen_bn(weight, bias, running_mean, running_var, eps=1e-5):
     return scale.float(), shift.float()
 
 
-def conv2d(x: View, pc: PackedConv, y: View, relu: bool = False, relu_upto: Optional[int] = None,
-           res: Optional[View] = None, res_upsample: bool = False, in_relu: bool = False) -> None:
-    lib = _lib.load()
+def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, res, res_upsample, in_relu) -> None:
     _need_gpu(x.t, "conv2d")
     n, h, w = x.nhw
-    d = ConvDesc()
     d.x, d.x_cs, d.x_co = x.t.data_ptr(), x.cs, x.co
     d.w = pc.w.data_ptr()
     d.scale, d.shift = pc.scale.data_ptr(), pc.shift.data_ptr()
@@ -122,7 +119,32 @@ def conv2d(x: View, pc: PackedConv, y: View, relu: bool = False, relu_upto: Opti
     d.ksize, d.stride = pc.k, pc.stride
     d.relu_upto = (pc.cout if relu else 0) if relu_upto is None else relu_upto
     d.in_relu = int(in_relu)
+
+
+def conv2d(x: View, pc: PackedConv, y: View, relu: bool = False, relu_upto: Optional[int] = None,
+           res: Optional[View] = None, res_upsample: bool = False, in_relu: bool = False) -> None:
+    lib = _lib.load()
+    d = ConvDesc()
+    _fill_desc(d, x, pc, y, relu, relu_upto, res, res_upsample, in_relu)
     check(lib.cmk_conv2d_nhwc(ctypes.byref(d), _stream()), "cmk_conv2d_nhwc")
+
+
+def conv2d_multi(xs: Sequence[View], pcs: Sequence[PackedConv], ys: Sequence[View], relu: bool = False,
+                 relu_upto: Optional[int] = None) -> None:
+    """One launch over several inputs that share the packed weights (pcs[i].w is the same tensor; scale/shift may differ)."""
+    lib = _lib.load()
+    n = len(xs)
+    descs = (ConvDesc * n)()
+    for i in range(n):
+        assert pcs[i].w.data_ptr() == pcs[0].w.data_ptr()
+        _fill_desc(descs[i], xs[i], pcs[i], ys[i], relu, relu_upto, None, False, False)
+    check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi")
+
+
+def conv_out_multi(xs: Sequence[View], pcs: Sequence[PackedConv], **kw) -> List[View]:
+    ys = [View(torch.empty((x.t.shape[0], x.t.shape[1], x.t.shape[2], pcs[0].cout), dtype=torch.float32, device=x.t.device)) for x in xs]
+    conv2d_multi(xs, pcs, ys, **kw)
+    return ys
 
 
 def conv_out(x: View, pc: PackedConv, **kw) -> View:
@@ -326,10 +348,27 @@ def conv2d(x, pc, y, **kw):  # noqa: F811
     nbytes = 4.0 * (n * h * w * pc.cin + n * ho * wo * pc.cout + pc.cin * pc.cout * taps)
     c32 = (pc.cout + 31) // 32
     wn = c32 if c32 <= 7 else 4
-    wm = 1 if (pc.stride == 2 or wn > 4) else 2
-    key = "conv_igemm_kernel<{},{},{},{}>".format(taps, pc.stride, wm, wn)
+    key = "conv_igemm_kernel<{},{},*,{},*>".format(taps, pc.stride, wn)      # WM / tile shape are picked per layer by the host cost model
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _conv2d_plain(x, pc, y, **kw)
     e1.record()
     PROFILE.append((key, flops, nbytes, e0, e1, (n, h, w, pc.cin, pc.cout, pc.k, pc.stride)))
+
+
+_conv2d_multi_plain = conv2d_multi
+
+
+def conv2d_multi(xs, pcs, ys, **kw):  # noqa: F811
+    if PROFILE is None:
+        return _conv2d_multi_plain(xs, pcs, ys, **kw)
+    pc = pcs[0]
+    taps = pc.k * pc.k
+    flops = sum(2.0 * y.t.shape[0] * y.t.shape[1] * y.t.shape[2] * pc.cin * pc.cout * taps for y in ys)
+    nbytes = sum(4.0 * (x.t.shape[0] * x.t.shape[1] * x.t.shape[2] * pc.cin + y.t.shape[0] * y.t.shape[1] * y.t.shape[2] * pc.cout) for x, y in zip(xs, ys))
+    nbytes += 4.0 * pc.cin * pc.cout * taps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _conv2d_multi_plain(xs, pcs, ys, **kw)
+    e1.record()
+    PROFILE.append(("conv_igemm_kernel<{},1,multi,cout{}>".format(taps, pc.cout), flops, nbytes, e0, e1, None))

@@ -46,6 +46,10 @@ typedef struct {
     int in_relu;                                /* ReLU applied to the input while staging (fpn.py:34) */
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
+/* Same conv applied to up to 5 inputs of different H x W in ONE launch (the FCOS towers/predictors share their weights
+ * across the FPN levels, fcos.py:227-238).  All descriptors must share w, Cin, Cout, ksize, stride, views and flags and
+ * carry no residual; x, y, N, H, W, scale, shift may differ. */
+int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* stream);
 /* number of floats of the packed layout for (Cout, Cin, k): taps * ceil(Cin/16) * cout_pad * 16 */
 int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize);
 int cmk_conv_cout_pad(int Cout);

@@ -130,3 +130,45 @@ def test_groupnorm_relu(dev, h, w):
     ops.groupnorm_relu_(t, gamma.to(dev), beta.to(dev))
     torch.cuda.synchronize()
     _close(t.permute(0, 3, 1, 2), ref, 2e-5)
+
+
+def test_conv_multi_level_launch(dev):
+    """FCOS-style: one launch over 5 inputs of different sizes sharing the weights; per-problem scale/shift."""
+    shapes = [(25, 40), (13, 20), (7, 10), (4, 5), (2, 3)]
+    wt = _rand((5, 256, 3, 3), 51, 0.03)
+    base = ops.PackedConv(wt, None, None, dev)
+    xs, pcs, refs = [], [], []
+    for l, (h, w) in enumerate(shapes):
+        x = _rand((2, 256, h, w), 60 + l)
+        sc = torch.tensor([1.0 + l] * 4 + [1.0])
+        sh = _rand((5,), 70 + l, 0.1)
+        pc = ops.PackedConv.__new__(ops.PackedConv)
+        pc.__dict__.update(base.__dict__)
+        pc.scale, pc.shift = sc.to(dev), sh.to(dev)
+        ref = F.conv2d(x, wt, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        ref[:, :4] = F.relu(ref[:, :4])
+        xs.append(ops.as_view(x.to(dev))); pcs.append(pc); refs.append(ref)
+    ys = ops.conv_out_multi(xs, pcs, relu_upto=4)
+    torch.cuda.synchronize()
+    for y, ref in zip(ys, refs):
+        _close(y.nchw(), ref)
+
+
+@pytest.mark.parametrize("variant", ["2x16", "2x32", "1x16", "1x32"])
+def test_conv_tile_variants_forced(dev, variant):
+    """Every (WM, sub-tile shape) variant of the 3x3 kernel gives the same result (the cost model only picks among them).
+    The override is read once per process, so each variant runs in a fresh interpreter."""
+    import os, subprocess, sys
+    code = (
+        "import sys, torch, torch.nn.functional as F; sys.path.insert(0, %r)\n"
+        "from centermask2_amd import ops\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "for (n,h,w,cin,cout) in [(2,37,45,64,128),(1,20,70,32,96),(1,9,33,48,160)]:\n"
+        "    x = torch.randn((n,cin,h,w), generator=g); wt = torch.randn((cout,cin,3,3), generator=g)*0.05\n"
+        "    ref = F.relu(F.conv2d(x, wt, None, padding=1))\n"
+        "    y = ops.conv_out(ops.as_view(x.cuda()), ops.PackedConv(wt, None, None, 'cuda'), relu=True)\n"
+        "    torch.cuda.synchronize()\n"
+        "    err = (y.nchw().cpu()-ref).abs().max().item(); assert err < 2e-4*max(1,ref.abs().max().item()), err\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CMK_CONV_VARIANT=variant), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
