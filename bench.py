@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--body", default="V-39-eSE")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="use the library's cost model instead of timing the conv tile variants at start-up")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,8 +165,11 @@ def main():
 
     use_graph = not args.no_graph
     graph = None
+    from centermask2_amd import ops
     with torch.no_grad():
-        out, rec = step_eager()            # first call: packs weights, sets kernel attributes
+        ops.set_autotune(not args.no_autotune)   # first call: packs weights, sets kernel attributes, times the conv tile variants
+        out, rec = step_eager()
+        ops.set_autotune(False)
         torch.cuda.synchronize()
         if use_graph:
             try:
@@ -232,6 +236,7 @@ def main():
                                        "3x800x1280, end-to-end (BASELINE configs[3])".format(args.body, B),
                            "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp{}".format(world),
                            "launch": "hip-graph" if graph is not None else "eager",
+                           "conv_variants": "autotuned at start-up ({} problems)".format(len(ops.tuned_variants())) if not args.no_autotune else "cost model",
                            "collective": "RCCL all_gather of {} B/img records".format(rec.shape[1] * 4) if world > 1 else "none",
                            "candidates_per_image": cand, "detections_per_image": dets,
                            "weights": "seeded random-init, reference state-dict keys"},

@@ -22,6 +22,7 @@ class ConvDesc(Structure):
         ("y", c_void_p), ("y_cs", c_int), ("y_co", c_int),
         ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
         ("ksize", c_int), ("stride", c_int), ("relu_upto", c_int), ("in_relu", c_int),
+        ("tune_wm", c_int), ("tune_sc", c_int), ("tune_wn", c_int),
     ]
 
 

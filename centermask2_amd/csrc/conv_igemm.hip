@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
 // ---------------------------------------------------------------------------------------------------------------
 // host side: variant menu + cost model
 // ---------------------------------------------------------------------------------------------------------------
-struct Variant { int wm, sc; };
+struct Variant { int wm, sc, wn; };
 
 template <int TAPS, int STRIDE, int WM, int WN, int SC>
 static int launch(ConvArgs& a, int grid_y, hipStream_t st) {
@@ -341,54 +341,60 @@ static int launch(ConvArgs& a, int grid_y, hipStream_t st) {
     return check_launch("conv_igemm");
 }
 
-// cost of running `blocks` equal workgroups of BM pixels with `resident` per CU on 256 CUs: full rounds keep every CU at
-// `resident` workgroups; the last round spreads round-robin.  eff(j) = matrix-pipe utilisation with j workgroups on a CU.
-static double round_cost(long blocks, int resident, int bm) {
+// cost of running `blocks` equal workgroups with `resident` per CU on 256 CUs: full rounds keep every CU at `resident`
+// workgroups; the last round spreads round-robin.  eff(j) = matrix-pipe utilisation with j workgroups on a CU.
+static double round_cost(long blocks, int resident, double wg_cost) {
     static const double eff[4] = {1.0, 0.70, 0.90, 0.95};
     const long slots = 256L * resident;
     long full = blocks / slots, rem = blocks % slots;
-    double c = (double)full * resident * bm / eff[resident];
+    double c = (double)full * resident * wg_cost / eff[resident];
     if (rem) {
         int j = (int)((rem + 255) / 256);
-        c += (double)j * bm / eff[j];
+        c += (double)j * wg_cost / eff[j];
     }
     return c;
 }
 
-template <int TAPS, int STRIDE, int WN>
-static Variant choose_variant(const ConvArgs& a, int grid_y) {
-    static const char* force = getenv("CMK_CONV_VARIANT");   // e.g. "2x16", "1x32" (debug / tuning)
-    Variant best{1, 16};
+static bool variant_ok(int taps, int stride, int cout32, int wm, int sc, int wn) {
+    if (wn < 1 || wn > 7 || (wm != 1 && wm != 2) || (sc != 16 && sc != 32)) return false;
+    if (cout32 <= 7 ? (cout32 % wn != 0) : (wn != 1 && wn != 2 && wn != 4)) return false;   // packed cout_pad must be a multiple of 32*wn
+    if (wm == 2 && (wn > 4 || stride == 2)) return false;
+    if (taps == 1 && sc != 32) return false;
+    if (stride == 2 && sc != 16) return false;
+    return true;
+}
+
+// Default choice when the caller gives no tuned variant: minimise modelled time over the menu.
+static Variant choose_variant(const ConvArgs& a, int taps, int stride, int cout32) {
+    Variant best{1, taps == 1 ? 32 : 16, cout32 <= 7 ? cout32 : 4};
     double best_cost = 1e300;
-    for (int wm = 2; wm >= 1; --wm) {
-        if (wm == 2 && (WN > 4 || STRIDE == 2)) continue;
-        for (int sc = 16; sc <= 32; sc += 16) {
-            if (TAPS == 1 && sc == 16) continue;          // 1x1 has no spatial tile shape
-            if (STRIDE == 2 && sc == 32) continue;        // halo of a 4x32 stride-2 tile does not pay
-            if (force && (force[0] - '0' != wm || atoi(force + 2) != sc) && !(TAPS == 1 && force[0] - '0' == wm)) continue;
-            const int sr = 32 / sc, bm = 128 * wm;
-            const int th = TAPS == 9 ? sr * 4 * wm : 1, tw = TAPS == 9 ? sc : bm;
-            long blocks = 0;
-            for (int i = 0; i < a.nprob; ++i)
-                blocks += TAPS == 9 ? (long)a.p[i].N * cdiv(a.p[i].Ho, th) * cdiv(a.p[i].Wo, tw) : (a.p[i].total_pix + bm - 1) / bm;
-            blocks *= grid_y;
-            // residency as Geo computes it
-            const int apix = TAPS == 9 ? ((th - 1) * STRIDE + 3) * ((tw - 1) * STRIDE + 3) : bm;
-            const int abytes = apix * PST * 4, bbytes = 32 * WN * PST * 4;
-            const int occ = occ_of(wm, WN, STRIDE);
-            const bool adb = (2 * abytes + 2 * bbytes) * occ <= LDS_CU;
-            const int lds = (adb ? 2 : 1) * abytes + 2 * bbytes;
-            const int resident = lds * occ <= LDS_CU ? occ : (lds * 2 <= LDS_CU ? 2 : 1);
-            double cost = round_cost(blocks, resident, bm) * (wm == 1 ? 1.03 : 1.0);
-            if (cost < best_cost) { best_cost = cost; best = Variant{wm, sc}; }
-        }
-    }
+    const int cout_pad32 = cout32 <= 7 ? cout32 : cdiv(cout32, 4) * 4;
+    for (int wn = 7; wn >= 1; --wn)
+        for (int wm = 2; wm >= 1; --wm)
+            for (int sc = 16; sc <= 32; sc += 16) {
+                if (!variant_ok(taps, stride, cout32, wm, sc, wn)) continue;
+                const int sr = 32 / sc, bm = 128 * wm;
+                const int th = taps == 9 ? sr * 4 * wm : 1, tw = taps == 9 ? sc : bm;
+                long blocks = 0;
+                for (int i = 0; i < a.nprob; ++i)
+                    blocks += taps == 9 ? (long)a.p[i].N * cdiv(a.p[i].Ho, th) * cdiv(a.p[i].Wo, tw) : (a.p[i].total_pix + bm - 1) / bm;
+                blocks *= cout_pad32 / wn;
+                const int apix = taps == 9 ? ((th - 1) * stride + 3) * ((tw - 1) * stride + 3) : bm;
+                const int abytes = apix * PST * 4, bbytes = 32 * wn * PST * 4;
+                const int occ = occ_of(wm, wn, stride);
+                const bool adb = (2 * abytes + 2 * bbytes) * occ <= LDS_CU;
+                const int lds = (adb ? 2 : 1) * abytes + 2 * bbytes;
+                const int resident = lds * occ <= LDS_CU ? occ : (lds * 2 <= LDS_CU ? 2 : 1);
+                // per-workgroup time ~ MFMA cycles per step + a fixed per-step overhead (barrier, LDS fill, address math)
+                const double wg_cost = 512.0 * wm * wn + 260.0;
+                double cost = round_cost(blocks, resident, wg_cost);
+                if (cost < best_cost) { best_cost = cost; best = Variant{wm, sc, wn}; }
+            }
     return best;
 }
 
 template <int TAPS, int STRIDE, int WN>
-static int dispatch_variant(ConvArgs& a, int grid_y, hipStream_t st) {
-    Variant v = choose_variant<TAPS, STRIDE, WN>(a, grid_y);
+static int dispatch_variant(ConvArgs& a, int grid_y, Variant v, hipStream_t st) {
     if constexpr (TAPS == 1) {
         if constexpr (WN <= 4) { if (v.wm == 2) return launch<1, 1, 2, WN, 32>(a, grid_y, st); }
         return launch<1, 1, 1, WN, 32>(a, grid_y, st);
@@ -403,18 +409,18 @@ static int dispatch_variant(ConvArgs& a, int grid_y, hipStream_t st) {
 }
 
 template <int TAPS, int STRIDE>
-static int dispatch_wn(ConvArgs& a, int cout32, hipStream_t st) {
-    int wn = cout32 <= 7 ? cout32 : 4;
-    int grid_y = cout32 <= 7 ? 1 : cdiv(cout32, 4);
-    a.cout_pad = grid_y * wn * 32;
-    switch (wn) {
-        case 1: return dispatch_variant<TAPS, STRIDE, 1>(a, grid_y, st);
-        case 2: return dispatch_variant<TAPS, STRIDE, 2>(a, grid_y, st);
-        case 3: return dispatch_variant<TAPS, STRIDE, 3>(a, grid_y, st);
-        case 4: return dispatch_variant<TAPS, STRIDE, 4>(a, grid_y, st);
-        case 5: return dispatch_variant<TAPS, STRIDE, 5>(a, grid_y, st);
-        case 6: return dispatch_variant<TAPS, STRIDE, 6>(a, grid_y, st);
-        case 7: return dispatch_variant<TAPS, STRIDE, 7>(a, grid_y, st);
+static int dispatch_wn(ConvArgs& a, int cout32, Variant v, hipStream_t st) {
+    const int cout_pad32 = cout32 <= 7 ? cout32 : cdiv(cout32, 4) * 4;
+    a.cout_pad = cout_pad32 * 32;
+    const int grid_y = cout_pad32 / v.wn;
+    switch (v.wn) {
+        case 1: return dispatch_variant<TAPS, STRIDE, 1>(a, grid_y, v, st);
+        case 2: return dispatch_variant<TAPS, STRIDE, 2>(a, grid_y, v, st);
+        case 3: return dispatch_variant<TAPS, STRIDE, 3>(a, grid_y, v, st);
+        case 4: return dispatch_variant<TAPS, STRIDE, 4>(a, grid_y, v, st);
+        case 5: return dispatch_variant<TAPS, STRIDE, 5>(a, grid_y, v, st);
+        case 6: return dispatch_variant<TAPS, STRIDE, 6>(a, grid_y, v, st);
+        case 7: return dispatch_variant<TAPS, STRIDE, 7>(a, grid_y, v, st);
     }
     return fail(CMK_EINVAL, "conv: bad WN%s", "");
 }
@@ -455,10 +461,18 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     if (a.res_mode == 2 && (a.Hr * 2 < a.p[0].Ho || a.Wr * 2 < a.p[0].Wo)) return fail(CMK_EINVAL, "conv: upsampled residual too small%s", "");
     a.relu_upto = d->relu_upto; a.in_relu = d->in_relu;
     const int cout32 = (d->Cout + 31) / 32;
+    const int taps = d->ksize * d->ksize;
     hipStream_t st = (hipStream_t)stream;
-    if (d->ksize == 1) return dispatch_wn<1, 1>(a, cout32, st);
-    if (d->stride == 1) return dispatch_wn<9, 1>(a, cout32, st);
-    return dispatch_wn<9, 2>(a, cout32, st);
+    Variant v;
+    if (d->tune_wm || d->tune_sc || d->tune_wn) {      // the caller measured and picked a variant
+        v = Variant{d->tune_wm, d->tune_sc, d->tune_wn};
+        if (!variant_ok(taps, d->stride, cout32, v.wm, v.sc, v.wn)) return fail(CMK_EINVAL, "conv: variant not available for this shape%s", "");
+    } else {
+        v = choose_variant(a, taps, d->stride, cout32);
+    }
+    if (d->ksize == 1) return dispatch_wn<1, 1>(a, cout32, v, st);
+    if (d->stride == 1) return dispatch_wn<9, 1>(a, cout32, v, st);
+    return dispatch_wn<9, 2>(a, cout32, v, st);
 }
 
 }  // namespace cmk
@@ -489,7 +503,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
         if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
-            b->y_co != a->y_co || b->res_mode != 0)
+            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn)
             return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
     }
     return run(descs, n, stream);

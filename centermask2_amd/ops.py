@@ -121,12 +121,71 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
     d.in_relu = int(in_relu)
 
 
+# ---- tile-variant autotuning (host side; the library itself stays stateless) -----------------------------------
+AUTOTUNE = False          # when True, the first call of every distinct conv problem times the variant menu (needs an idle, non-capturing stream)
+_TUNED = {}               # problem key -> (wm, sc, wn)
+
+
+def set_autotune(flag: bool) -> None:
+    global AUTOTUNE
+    AUTOTUNE = bool(flag)
+
+
+def tuned_variants() -> dict:
+    return dict(_TUNED)
+
+
+def _tune(descs, n, key) -> None:
+    """Time every available (wm, sc, wn) variant on the real buffers (results are bitwise identical across variants)
+    and remember the fastest.  Variants the library rejects for this shape are skipped."""
+    lib = _lib.load()
+    st = _stream()
+
+    def run():
+        return lib.cmk_conv2d_nhwc_multi(descs, n, st) if n > 1 else lib.cmk_conv2d_nhwc(ctypes.byref(descs[0]), st)
+
+    best, best_ms = (0, 0, 0), float("inf")
+    for wn in range(1, 8):
+        for wm in (1, 2):
+            for sc in (16, 32):
+                for i in range(n):
+                    descs[i].tune_wm, descs[i].tune_sc, descs[i].tune_wn = wm, sc, wn
+                if run() != 0:
+                    continue                      # not on the menu for this shape
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                run()
+                run()
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if ms < best_ms:
+                    best, best_ms = (wm, sc, wn), ms
+    _TUNED[key] = best
+
+
+def _apply_tuning(descs, n, key) -> None:
+    tv = _TUNED.get(key)
+    if tv is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+        _tune(descs, n, key)
+        tv = _TUNED[key]
+    tv = tv or (0, 0, 0)
+    for i in range(n):
+        descs[i].tune_wm, descs[i].tune_sc, descs[i].tune_wn = tv
+
+
+def _problem_key(descs, n):
+    d = descs[0]
+    return (d.ksize, d.stride, d.Cin, d.Cout, d.x_cs, d.y_cs, d.res_mode, tuple((descs[i].N, descs[i].H, descs[i].W) for i in range(n)))
+
+
 def conv2d(x: View, pc: PackedConv, y: View, relu: bool = False, relu_upto: Optional[int] = None,
            res: Optional[View] = None, res_upsample: bool = False, in_relu: bool = False) -> None:
     lib = _lib.load()
-    d = ConvDesc()
-    _fill_desc(d, x, pc, y, relu, relu_upto, res, res_upsample, in_relu)
-    check(lib.cmk_conv2d_nhwc(ctypes.byref(d), _stream()), "cmk_conv2d_nhwc")
+    descs = (ConvDesc * 1)()
+    _fill_desc(descs[0], x, pc, y, relu, relu_upto, res, res_upsample, in_relu)
+    _apply_tuning(descs, 1, _problem_key(descs, 1))
+    check(lib.cmk_conv2d_nhwc(ctypes.byref(descs[0]), _stream()), "cmk_conv2d_nhwc")
 
 
 def conv2d_multi(xs: Sequence[View], pcs: Sequence[PackedConv], ys: Sequence[View], relu: bool = False,
@@ -138,6 +197,7 @@ def conv2d_multi(xs: Sequence[View], pcs: Sequence[PackedConv], ys: Sequence[Vie
     for i in range(n):
         assert pcs[i].w.data_ptr() == pcs[0].w.data_ptr()
         _fill_desc(descs[i], xs[i], pcs[i], ys[i], relu, relu_upto, None, False, False)
+    _apply_tuning(descs, n, _problem_key(descs, n))
     check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi")
 
 

@@ -44,6 +44,11 @@ typedef struct {
     int stride;                                 /* 1 or 2 */
     int relu_upto;                              /* ReLU applied to output channels < relu_upto */
     int in_relu;                                /* ReLU applied to the input while staging (fpn.py:34) */
+    /* optional tile variant picked by the caller's autotuner (all 0 = let the library's cost model choose):
+     * tune_wm in {1,2} (128 or 256 pixels per workgroup), tune_sc in {16,32} (sub-tile 2x16 or 1x32 pixels; 32 for 1x1),
+     * tune_wn in 1..7 (32*tune_wn output channels per workgroup; must divide the padded Cout).  Results are bitwise
+     * identical across variants (the K order per output does not depend on the tile). */
+    int tune_wm; int tune_sc; int tune_wn;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
 /* Same conv applied to up to 5 inputs of different H x W in ONE launch (the FCOS towers/predictors share their weights

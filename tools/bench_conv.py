@@ -16,7 +16,9 @@ SHAPES = [  # name, H, W, Cin, Cout, k, stride
     ("fcos_p3", 100, 160, 256, 256, 3, 1), ("fcos_p4", 50, 80, 256, 256, 3, 1), ("fcos_p5", 25, 40, 256, 256, 3, 1),
     ("cls_p3", 100, 160, 256, 80, 3, 1),
 ]
-print("%-10s %8s %8s %8s" % ("layer", "ms", "TFLOP/s", "GB/s(alg)"))
+TUNE = len(sys.argv) > 1 and sys.argv[1] == "tune"
+ops.set_autotune(TUNE)
+print("%-10s %8s %8s %8s  %s" % ("layer", "ms", "TFLOP/s", "GB/s(alg)", "autotuned" if TUNE else "cost model"))
 tot_ms = tot_fl = 0
 for name, h, w, cin, cout, k, s in SHAPES:
     x = View(torch.randn((B, h, w, cin), device=dev))
@@ -34,6 +36,7 @@ for name, h, w, cin, cout, k, s in SHAPES:
     ho, wo = y.t.shape[1], y.t.shape[2]
     fl = 2.0 * B * ho * wo * cin * cout * k * k
     by = 4.0 * (B * h * w * cin + B * ho * wo * cout + cin * cout * k * k)
-    print("%-10s %8.3f %8.1f %8.0f" % (name, ms, fl / ms / 1e9, by / ms / 1e6))
+    tv = [v for k_, v in ops.tuned_variants().items() if k_[2] == cin and k_[3] == cout and k_[7][0][1] == h]
+    print("%-10s %8.3f %8.1f %8.0f  %s" % (name, ms, fl / ms / 1e9, by / ms / 1e6, tv[-1] if tv else ""))
     tot_ms += ms; tot_fl += fl
 print("sum %.2f ms, %.1f TFLOP/s" % (tot_ms, tot_fl / tot_ms / 1e9))
