@@ -397,6 +397,14 @@ PROFILE = None       # when a list, conv2d appends (kernel_key, flops, algorithm
 _conv2d_plain = conv2d
 
 
+def _kernel_name(taps, stride, tv) -> str:
+    """The template instantiation rocprofv3 will report: conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>."""
+    if not tv or tv == (0, 0, 0):
+        return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
+    wm, sc, wn = tv
+    return "conv_igemm_kernel<{}, {}, {}, {}, {}>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
+
+
 def conv2d(x, pc, y, **kw):  # noqa: F811
     if PROFILE is None:
         return _conv2d_plain(x, pc, y, **kw)
@@ -406,9 +414,9 @@ def conv2d(x, pc, y, **kw):  # noqa: F811
     taps = pc.k * pc.k
     flops = 2.0 * n * ho * wo * pc.cin * pc.cout * taps
     nbytes = 4.0 * (n * h * w * pc.cin + n * ho * wo * pc.cout + pc.cin * pc.cout * taps)
-    c32 = (pc.cout + 31) // 32
-    wn = c32 if c32 <= 7 else 4
-    key = "conv_igemm_kernel<{},{},*,{},*>".format(taps, pc.stride, wn)      # WM / tile shape are picked per layer by the host cost model
+    descs = (ConvDesc * 1)()
+    _fill_desc(descs[0], x, pc, y, kw.get("relu", False), kw.get("relu_upto"), kw.get("res"), kw.get("res_upsample", False), kw.get("in_relu", False))
+    key = _kernel_name(taps, pc.stride, _TUNED.get(_problem_key(descs, 1)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _conv2d_plain(x, pc, y, **kw)
@@ -431,4 +439,7 @@ def conv2d_multi(xs, pcs, ys, **kw):  # noqa: F811
     e0.record()
     _conv2d_multi_plain(xs, pcs, ys, **kw)
     e1.record()
-    PROFILE.append(("conv_igemm_kernel<{},1,multi,cout{}>".format(taps, pc.cout), flops, nbytes, e0, e1, None))
+    descs = (ConvDesc * len(xs))()
+    for i in range(len(xs)):
+        _fill_desc(descs[i], xs[i], pcs[i], ys[i], kw.get("relu", False), kw.get("relu_upto"), None, False, False)
+    PROFILE.append((_kernel_name(taps, 1, _TUNED.get(_problem_key(descs, len(xs)))), flops, nbytes, e0, e1, None))
