@@ -129,7 +129,9 @@ def main():
     ap.add_argument("--body", default="V-39-eSE")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-autotune", action="store_true", help="use the library's cost model instead of timing the conv tile variants at start-up")
+    ap.add_argument("--no-autotune", action="store_true", help="use the library's cost model instead of the measured conv tile-variant table")
+    ap.add_argument("--tune-file", default=None, help="conv variant table (default: centermask2_amd/tuned/mi355x_<body>_b<B>_800x1280.json)")
+    ap.add_argument("--save-tuned", action="store_true", help="write the variant table after start-up tuning")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,11 +168,17 @@ def main():
     use_graph = not args.no_graph
     graph = None
     from centermask2_amd import ops
+    tune_file = args.tune_file or os.path.join(ROOT, "centermask2_amd", "tuned", "mi355x_{}_b{}_800x1280.json".format(args.body, B))
+    n_loaded = ops.load_tuned(tune_file) if (os.path.exists(tune_file) and not args.no_autotune) else 0
     with torch.no_grad():
-        ops.set_autotune(not args.no_autotune)   # first call: packs weights, sets kernel attributes, times the conv tile variants
-        out, rec = step_eager()
+        ops.set_autotune(not args.no_autotune)   # first call: packs weights, sets kernel attributes; conv problems missing from the
+        out, rec = step_eager()                  # shipped variant table are timed here (outside the timed region)
         ops.set_autotune(False)
         torch.cuda.synchronize()
+        n_tuned = len(ops.tuned_variants())
+        if args.save_tuned and rank == 0:
+            os.makedirs(os.path.dirname(tune_file), exist_ok=True)
+            ops.save_tuned(tune_file)
         if use_graph:
             try:
                 side = torch.cuda.Stream()
@@ -236,7 +244,8 @@ def main():
                                        "3x800x1280, end-to-end (BASELINE configs[3])".format(args.body, B),
                            "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp{}".format(world),
                            "launch": "hip-graph" if graph is not None else "eager",
-                           "conv_variants": "autotuned at start-up ({} problems)".format(len(ops.tuned_variants())) if not args.no_autotune else "cost model",
+                           "conv_variants": "measured table: {} problems loaded from {}, {} timed at start-up".format(
+                               n_loaded, os.path.relpath(tune_file, ROOT), n_tuned - n_loaded) if not args.no_autotune else "library cost model",
                            "collective": "RCCL all_gather of {} B/img records".format(rec.shape[1] * 4) if world > 1 else "none",
                            "candidates_per_image": cand, "detections_per_image": dets,
                            "weights": "seeded random-init, reference state-dict keys"},

@@ -135,6 +135,35 @@ def tuned_variants() -> dict:
     return dict(_TUNED)
 
 
+def _key_to_str(key) -> str:
+    k, stride, cin, cout, xcs, ycs, res, shapes = key
+    return "k{}s{}_cin{}_cout{}_xcs{}_ycs{}_res{}_".format(k, stride, cin, cout, xcs, ycs, res) + "+".join("{}x{}x{}".format(*s) for s in shapes)
+
+
+def _str_to_key(s: str):
+    head, shapes = s.rsplit("_", 1)
+    f = head.split("_")
+    k, stride = f[0][1:].split("s")
+    vals = [int(f[1][3:]), int(f[2][4:]), int(f[3][3:]), int(f[4][3:]), int(f[5][3:])]
+    return (int(k), int(stride), vals[0], vals[1], vals[2], vals[3], vals[4], tuple(tuple(int(v) for v in t.split("x")) for t in shapes.split("+")))
+
+
+def save_tuned(path: str) -> None:
+    """Write the measured variant table (problem -> [wm, sc, wn]) as JSON; shipped tables live in centermask2_amd/tuned/."""
+    import json
+    with open(path, "w") as f:
+        json.dump({_key_to_str(k): list(v) for k, v in sorted(_TUNED.items(), key=lambda kv: _key_to_str(kv[0]))}, f, indent=0)
+
+
+def load_tuned(path: str) -> int:
+    import json
+    with open(path) as f:
+        table = json.load(f)
+    for k, v in table.items():
+        _TUNED[_str_to_key(k)] = tuple(v)
+    return len(table)
+
+
 def _tune(descs, n, key) -> None:
     """Time every available (wm, sc, wn) variant on the real buffers (results are bitwise identical across variants)
     and remember the fastest.  Variants the library rejects for this shape are skipped."""
