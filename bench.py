@@ -77,6 +77,15 @@ def roofline_leg(model, x, sizes):
         "per_kernel": {k: {"ms": round(a["ms"], 3), "TFLOP/s": round(a["flops"] / a["ms"] / 1e9, 1), "launches": a["launches"]}
                        for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
     }
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (a process cannot
+    # read the PMCs of its own launches); tools/pmc_traffic.py writes them, with the gfx950 corrections, to profiles/.
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath)).get(dom)
+        if t:
+            roof["traffic"] = round(t["hbm_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            roof["alg_bytes_per_launch"] = round(d["bytes"] / d["launches"])
     return roof
 
 
