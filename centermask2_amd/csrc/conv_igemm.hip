@@ -57,6 +57,7 @@ struct ConvArgs {
     int x_cs, x_co, y_cs, y_co, res_cs, res_co, res_mode, Hr, Wr;
     int relu_upto, in_relu;
     int cout_pad;
+    int grid_y;   // N tiles; the N-tile index is the FASTEST block coordinate so the workgroups sharing an input tile run together (L2 reuse)
 };
 
 template <int TAPS, int STRIDE, int WM, int WN, int SC>
@@ -94,14 +95,15 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
     const int li = lane & 31;
 
     // ---- which problem (FPN level) and which tile ------------------------------------------------------------
+    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAXP; ++i)
-        if (i < a.nprob && (int)blockIdx.x >= a.p[i].tile_begin) pi = i;
+        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
     const ConvProblem& P = a.p[pi];
     const int H = P.H, W = P.W, Ho = P.Ho, Wo = P.Wo;
     const long total_pix = P.total_pix;
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bx - P.tile_begin;
     int n = 0, oh0 = 0, ow0 = 0;
     long pix0 = 0;
     if (TAPS == 9) {
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
     } else {
         pix0 = (long)tile * G::BM;
     }
-    const int co0 = blockIdx.y * G::BN;
+    const int co0 = by * G::BN;
     const int nchunks = a.Cin >> 4;
     const int total_steps = nchunks * TAPS;
 
@@ -337,7 +339,8 @@ static int launch(ConvArgs& a, int grid_y, hipStream_t st) {
             blocks += (int)((p.total_pix + G::BM - 1) / G::BM);
         }
     }
-    hipLaunchKernelGGL(kern, dim3(blocks, grid_y), dim3(256), G::LDS_BYTES, st, a);
+    a.grid_y = grid_y;
+    hipLaunchKernelGGL(kern, dim3(blocks * grid_y), dim3(256), G::LDS_BYTES, st, a);
     return check_launch("conv_igemm");
 }
 

@@ -58,9 +58,12 @@ class GeneralizedRCNN(nn.Module):
     def preprocess_image(self, batched_inputs: List[Dict[str, torch.Tensor]]) -> ImageList:
         """Normalise and batch: (x - mean) / std, zero-pad right/bottom to the backbone's size divisibility
         (d2 GeneralizedRCNN.preprocess_image; deploy_utils.py:76-98 pads to a fixed 1344 instead)."""
+        from .. import ops
         images = [x["image"].to(self.device) for x in batched_inputs]
-        images = [(x.float() - self.pixel_mean) / self.pixel_std for x in images]
-        return ImageList.from_tensors(images, self.backbone.size_divisibility)
+        images = [im if im.dtype in (torch.uint8, torch.float32) else im.float() for im in images]
+        batch, sizes = ops.preprocess_images(images, self.pixel_mean.flatten().tolist(), self.pixel_std.flatten().tolist(),
+                                             self.backbone.size_divisibility)
+        return ImageList(batch, sizes)
 
     # -- device-only fast path --------------------------------------------------------------------------------------
     def inference_padded(self, images: torch.Tensor, image_sizes: Sequence[Tuple[int, int]], want=()) -> dict:

@@ -472,3 +472,41 @@ def conv2d_multi(xs, pcs, ys, **kw):  # noqa: F811
     for i in range(len(xs)):
         _fill_desc(descs[i], xs[i], pcs[i], ys[i], kw.get("relu", False), kw.get("relu_upto"), None, False, False)
     PROFILE.append((_kernel_name(taps, 1, _TUNED.get(_problem_key(descs, len(xs)))), flops, nbytes, e0, e1, None))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# before / after the model
+# ---------------------------------------------------------------------------------------------------------------
+def preprocess_images(images: Sequence[torch.Tensor], mean, std, size_divisibility: int = 32, fixed_size: Optional[int] = None):
+    """CHW uint8/float32 images on the GPU -> (N,3,H,W) float32 normalised, zero-padded right/bottom; returns (batch, sizes).
+    fixed_size=1344 reproduces deploy_utils.single_preprocessing; otherwise the batch max rounded up to the divisibility."""
+    lib = _lib.load()
+    sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+    if fixed_size:
+        H = W = int(fixed_size)
+    else:
+        d = max(1, size_divisibility)
+        H = (max(s[0] for s in sizes) + d - 1) // d * d
+        W = (max(s[1] for s in sizes) + d - 1) // d * d
+    dev = images[0].device
+    out = torch.empty((len(images), 3, H, W), dtype=torch.float32, device=dev)
+    m3, s3 = (ctypes.c_float * 3)(*[float(v) for v in mean]), (ctypes.c_float * 3)(*[float(v) for v in std])
+    for i, im in enumerate(images):
+        if not im.is_cuda or im.dtype not in (torch.uint8, torch.float32) or im.dim() != 3 or im.shape[0] != 3:
+            raise _lib.CmkError("preprocess_images: need (3,h,w) uint8/float32 CUDA tensors")
+        im = im.contiguous()
+        check(lib.cmk_preprocess_chw(im.data_ptr(), int(im.dtype == torch.uint8), out[i].data_ptr(), sizes[i][0], sizes[i][1], H, W,
+                                     m3, s3, _stream()), "cmk_preprocess_chw")
+    return out, sizes
+
+
+def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, height: int, width: int, threshold: float = 0.5) -> torch.Tensor:
+    """(R,S,S) float masks + (R,4) boxes -> (R,height,width) bool bitmasks."""
+    lib = _lib.load()
+    r, s = masks.shape[0], masks.shape[-1]
+    out = torch.empty((r, height, width), dtype=torch.uint8, device=masks.device)
+    if r:
+        _need_gpu(masks, "paste_masks")
+        check(lib.cmk_paste_masks(masks.contiguous().data_ptr(), boxes.contiguous().float().data_ptr(), r, s, height, width, float(threshold),
+                                  out.data_ptr(), _stream()), "cmk_paste_masks")
+    return out.bool()

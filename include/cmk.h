@@ -127,6 +127,18 @@ int cmk_mask_pool_concat(const float* masks /* (R,2S,2S) */, float* y, int y_cs,
 int cmk_mask_iou_score(const float* iou /* (R, classes_stride) */, int iou_cs, const float* scores, const int64_t* cls,
                        float* mask_scores, int R, void* stream);
 
+/* ---- input side: (x - mean) / std of one CHW image (uint8 if src_is_u8 else float32) into its zero-padded slot
+ * (3,H,W) of the batched NCHW tensor (deploy_utils.py:76-98; d2 preprocess_image + ImageList.from_tensors).  mean3 / std3
+ * are HOST arrays of 3 floats. ------------------------------------------------------------------------------------- */
+int cmk_preprocess_chw(const void* src, int src_is_u8, float* dst, int h, int w, int H, int W, const float* mean3,
+                       const float* std3, void* stream);
+
+/* ---- output side: paste (R,S,S) soft masks into (R,H,W) uint8 bitmasks at `threshold` (deploy_utils.py:151-156 ->
+ * d2 ROIMasks.to_bitmasks: bilinear grid_sample, align_corners=False, zero padding); boxes (R,4) are the rescaled and
+ * clipped output boxes. ------------------------------------------------------------------------------------------------ */
+int cmk_paste_masks(const float* masks, const float* boxes, int R, int S, int H, int W, float threshold, uint8_t* out,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

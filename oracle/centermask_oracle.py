@@ -444,3 +444,47 @@ def centermask_inference(sd, images: torch.Tensor, image_sizes: List[Tuple[int, 
 def flatten_to_tuple(res: dict):
     """single_flatten_to_tuple deploy_utils.py:117-126 field order."""
     return (res["locations"], res["mask_scores"], res["boxes"], res["classes"], res["pred_masks"], res["scores"])
+
+
+# --------------------------------------------------------------------------------------
+# pre / post-processing (deploy_utils.py:76-98, :129-158) — SURVEY §8(f) rows 1-2
+# --------------------------------------------------------------------------------------
+def preprocess(image_chw: torch.Tensor, mean=(103.53, 116.28, 123.675), std=(1.0, 1.0, 1.0), fixed_size=1344) -> torch.Tensor:
+    """single_preprocessing deploy_utils.py:76-98: (x - mean) / std, zero-pad right/bottom to fixed_size."""
+    x = (image_chw.float() - torch.tensor(mean).view(-1, 1, 1)) / torch.tensor(std).view(-1, 1, 1)
+    return F.pad(x, (0, fixed_size - x.shape[2], 0, fixed_size - x.shape[1]))
+
+
+def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, threshold=0.5) -> torch.Tensor:
+    """d2 ROIMasks.to_bitmasks -> paste_masks_in_image -> _do_paste_mask (source absent; published algorithm):
+    sample the (S,S) mask at every pixel centre with bilinear grid_sample(align_corners=False), then >= threshold."""
+    n = masks.shape[0]
+    if n == 0:
+        return torch.zeros((0, img_h, img_w), dtype=torch.bool)
+    x0, y0, x1, y1 = torch.split(boxes, 1, dim=1)
+    img_y = torch.arange(0, img_h, dtype=torch.float32) + 0.5
+    img_x = torch.arange(0, img_w, dtype=torch.float32) + 0.5
+    img_y = (img_y - y0) / (y1 - y0) * 2 - 1
+    img_x = (img_x - x0) / (x1 - x0) * 2 - 1
+    gx = img_x[:, None, :].expand(n, img_y.size(1), img_x.size(1))
+    gy = img_y[:, :, None].expand(n, img_y.size(1), img_x.size(1))
+    grid = torch.stack([gx, gy], dim=3)
+    img_masks = F.grid_sample(masks[:, None].float(), grid, align_corners=False)
+    return img_masks[:, 0] >= threshold
+
+
+def detector_postprocess(res: dict, h: int, w: int, mask_threshold=0.5) -> dict:
+    """deploy_utils.py:129-158."""
+    scale = 800 / min(h, w)
+    new_h, new_w = int(np.floor(h * scale)), int(np.floor(w * scale))
+    if max(new_h, new_w) > 1333:
+        scale = 1333 / max(new_h, new_w) * scale
+    boxes = res["boxes"].clone()
+    boxes[:, 0::2] *= 1 / scale
+    boxes[:, 1::2] *= 1 / scale
+    boxes = torch.stack((boxes[:, 0].clamp(0, w), boxes[:, 1].clamp(0, h), boxes[:, 2].clamp(0, w), boxes[:, 3].clamp(0, h)), dim=-1)
+    keep = ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
+    out = {k: v[keep] for k, v in res.items()}
+    out["boxes"] = boxes[keep]
+    out["pred_masks"] = paste_masks(out["pred_masks"][:, 0], out["boxes"], h, w, mask_threshold)
+    return out

@@ -89,3 +89,38 @@ def test_end_to_end_800x1280_matches_reference(dev, model):
         assert inst.pred_classes.dtype == torch.int64 and tuple(inst.pred_masks.shape[1:]) == (1, 28, 28)
     t = model.forward_tensor(x[:1], hw=[(800, 1280)])
     assert [tuple(v.shape[1:]) for v in t] == [(2,), (), (4,), (), (1, 28, 28), ()]
+
+
+def test_v99_backbone_and_full_model_run(dev):
+    """BASELINE config 5's body (V2-99-eSE: blocks [1,3,9,3]) through the same kernels; checked against the oracle at a
+    small size (the reference publishes no V-99 yaml, only the stage spec vovnet.py:90-98)."""
+    from centermask2_amd import synthetic as S
+    from centermask2_amd.structures import FakeImageList
+    from oracle import centermask_oracle as O
+    model, sd = build_gpu_model("V-99-eSE")
+    x = S.make_synthetic_images(1, 128, 192, seed0=555)
+    feats = model.backbone(x.to(dev))
+    ref = O.backbone_forward(sd, x, "V-99-eSE")
+    for k in ("p3", "p4", "p5", "p6", "p7"):
+        close(feats[k], ref[k], 1e-3, "V-99 " + k)
+    res = model.inference(FakeImageList(x.to(dev), [(128, 192)]), do_preprocess=False, do_postprocess=False)
+    torch.cuda.synchronize()
+    want = O.centermask_inference(sd, x, [(128, 192)], "V-99-eSE")[0]
+    assert len(res[0]) == want["scores"].shape[0]
+    assert torch.equal(res[0].pred_classes.cpu(), want["classes"]) and torch.equal(res[0].locations.cpu(), want["locations"])
+    close(res[0].pred_masks, want["pred_masks"], 1e-3)
+
+
+def test_inference_with_pre_and_postprocess(dev, model):
+    """GeneralizedRCNN.inference on raw uint8-valued images (tester.py:25-75 with do_preprocess/do_postprocess)."""
+    g = torch.Generator().manual_seed(77)
+    imgs = [{"image": torch.randint(0, 256, (3, 200, 300), generator=g).float().to(dev), "height": 100, "width": 150},
+            {"image": torch.randint(0, 256, (3, 180, 260), generator=g).to(torch.uint8).to(dev), "height": 90, "width": 130}]
+    out = model.inference(imgs)
+    assert len(out) == 2
+    for o, im in zip(out, imgs):
+        inst = o["instances"]
+        assert inst.image_size == (im["height"], im["width"])
+        if len(inst):
+            assert inst.pred_masks.dtype == torch.bool and tuple(inst.pred_masks.shape[1:]) == (im["height"], im["width"])
+            assert float(inst.pred_boxes.tensor[:, 2].max()) <= im["width"] and float(inst.pred_boxes.tensor.min()) >= 0

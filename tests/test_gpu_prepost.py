@@ -1,0 +1,50 @@
+"""-m gpu: pre/post-processing kernels vs the oracle.  d2's ROIMasks is absent from the reference
+tree, so the mask paste is "parity unpinned" beyond the oracle's restatement of the published algorithm."""
+import pytest
+import torch
+
+from centermask2_amd import ops, postprocess
+from centermask2_amd.structures import Boxes, Instances
+from oracle import centermask_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.float32])
+def test_preprocess_matches_reference_padding(dev, dtype):
+    g = torch.Generator().manual_seed(1)
+    imgs = [torch.randint(0, 256, (3, 37, 53), generator=g).to(dtype), torch.randint(0, 256, (3, 64, 21), generator=g).to(dtype)]
+    mean, std = (103.53, 116.28, 123.675), (1.0, 57.0, 2.0)
+    out, sizes = ops.preprocess_images([i.to(dev) for i in imgs], mean, std, fixed_size=96)
+    torch.cuda.synchronize()
+    assert sizes == [(37, 53), (64, 21)] and tuple(out.shape) == (2, 3, 96, 96)
+    for i, im in enumerate(imgs):
+        ref = O.preprocess(im, mean, std, fixed_size=96)
+        assert torch.allclose(out[i].cpu(), ref, rtol=0, atol=1e-5)
+    out2, _ = ops.preprocess_images([i.to(dev) for i in imgs], mean, std, size_divisibility=32)
+    assert tuple(out2.shape) == (2, 3, 64, 64)
+
+
+def test_detector_postprocess_and_mask_paste(dev):
+    g = torch.Generator().manual_seed(2)
+    n, h, w = 9, 427, 640                      # a COCO-sized original image; model ran at 800x1199
+    boxes = torch.rand((n, 4), generator=g) * torch.tensor([900.0, 600.0, 900.0, 600.0])
+    boxes[:, 2:] = boxes[:, :2] + torch.rand((n, 2), generator=g) * 500 + 1
+    boxes[0] = torch.tensor([-50.0, -20.0, 30.0, 40.0])             # partly outside
+    boxes[1] = torch.tensor([1300.0, 900.0, 1400.0, 950.0])         # fully outside after rescale -> dropped
+    masks = torch.rand((n, 1, 28, 28), generator=g)
+    res = dict(boxes=boxes, scores=torch.rand(n, generator=g), classes=torch.randint(0, 80, (n,), generator=g), locations=boxes[:, :2],
+               pred_masks=masks, mask_scores=torch.rand(n, generator=g))
+    ref = O.detector_postprocess(res, h, w)
+    inst = Instances((800, 1199), pred_boxes=Boxes(boxes.to(dev)), scores=res["scores"].to(dev), pred_classes=res["classes"].to(dev),
+                     locations=res["locations"].to(dev), pred_masks=masks.to(dev), mask_scores=res["mask_scores"].to(dev))
+    out = postprocess.detector_postprocess(inst, h, w)
+    torch.cuda.synchronize()
+    assert len(out) == ref["boxes"].shape[0] < n
+    assert torch.allclose(out.pred_boxes.tensor.cpu(), ref["boxes"], rtol=0, atol=1e-4)
+    assert torch.equal(out.pred_classes.cpu(), ref["classes"])
+    got, want = out.pred_masks.cpu(), ref["pred_masks"]
+    assert got.shape == want.shape and got.dtype == torch.bool
+    mismatch = (got != want).float().mean().item()
+    assert mismatch < 1e-5, mismatch          # pixels whose interpolated value sits within rounding of the 0.5 threshold
+    assert postprocess.resize_scale(427, 640) == pytest.approx(800 / 427)
