@@ -23,6 +23,7 @@ class ConvDesc(Structure):
         ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
         ("ksize", c_int), ("stride", c_int), ("relu_upto", c_int), ("in_relu", c_int),
         ("tune_wm", c_int), ("tune_sc", c_int), ("tune_wn", c_int),
+        ("w_wino", c_void_p),
     ]
 
 
@@ -39,6 +40,7 @@ SIGNATURES = {
     "cmk_conv2d_nhwc_multi": (c_int, [POINTER(ConvDesc), c_int, c_void_p]),
     "cmk_conv_packed_floats": (c_int64, [c_int, c_int, c_int]),
     "cmk_conv_cout_pad": (c_int, [c_int]),
+    "cmk_wino_packed_floats": (c_int64, [c_int, c_int]),
     "cmk_stem_conv_nchw3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_maxpool3x3s2_ceil_nhwc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_ese_gate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -310,6 +310,228 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) variant for 3x3 stride-1 convs, fused in one kernel (input transform, 16 frequency GEMMs on the
+// matrix pipe, output transform all on chip): 2.25x fewer MFMA flops than the direct form, still plain fp32 arithmetic
+// (transform matrices hold only 0, +-1, +-1/2; results differ from the direct kernel by fp32 rounding only).
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        per 4x4 input patch d -> 2x2 outputs, summed over input channels
+//   workgroup  = 16x16 output pixels (8x8 tiles) x 64 output channels, 4 waves = 2 (tile groups of 32) x 2 (32 couts)
+//   per 16-channel chunk: halo (18x18 px) -> LDS, every thread transforms one (tile, channel quad) into the 16 frequency
+//   planes V[f][tile][ci]; the pre-transformed weights U[f][co][ci] stream through LDS four frequencies at a time;
+//   each wave keeps 16 accumulators of 32x32 (256 registers, one wave per SIMD) — the output transform is then pure
+//   per-lane register arithmetic because a lane holds all 16 frequencies of its (tile, cout) entries.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int W_HALO = 18 * 18;
+constexpr int W_SH = W_HALO * PST;            // floats
+constexpr int W_SV = 16 * 64 * PST;
+constexpr int W_SU = 4 * 64 * PST;            // one group of 4 frequencies
+constexpr int W_LDS_BYTES = (W_SH + W_SV + 2 * W_SU) * 4;
+constexpr int W_A_ITERS = (W_HALO * 4 + 255) / 256;
+
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sH = smem;
+    float* sV = smem + W_SH;
+    float* sU = smem + W_SH + W_SV;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, li = lane & 31;
+    const int mg = wave >> 1, ng = wave & 1;
+
+    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
+    const ConvProblem& P = a.p[pi];
+    const int H = P.H, W = P.W;
+    const int tile = bx - P.tile_begin;
+    const int tw = tile % P.tiles_w;
+    const int t2 = tile / P.tiles_w;
+    const int th = t2 % P.tiles_h;
+    const int n = t2 / P.tiles_h;
+    const int oh0 = th * 16, ow0 = tw * 16;
+    const int co0 = by * 64;
+    const int nchunks = a.Cin >> 4;
+
+    // halo staging descriptors (clamped address + validity bit, as in the direct kernel)
+    const float* xin = P.x + (long)n * H * W * a.x_cs + a.x_co;
+    long g_off[W_A_ITERS];
+    unsigned ok = 0;
+#pragma unroll
+    for (int it = 0; it < W_A_ITERS; ++it) {
+        int idx = it * 256 + tid;
+        int pix = idx >> 2, q = idx & 3;
+        long off = 0;
+        if (idx < W_HALO * 4) {
+            int hr = pix / 18, hc = pix - hr * 18;
+            int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) { off = ((long)ih * W + iw) * a.x_cs + q * 4; ok |= 1u << it; }
+        }
+        g_off[it] = off;
+    }
+    f32x4 h_stage[W_A_ITERS];
+    f32x4 u_stage[4];
+    auto load_H = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < W_A_ITERS; ++it) h_stage[it] = *reinterpret_cast<const f32x4*>(xin + g_off[it] + chunk * 16);
+    };
+    auto store_H = [&]() {
+#pragma unroll
+        for (int it = 0; it < W_A_ITERS; ++it) {
+            int idx = it * 256 + tid;
+            if ((it + 1) * 256 <= W_HALO * 4 || idx < W_HALO * 4) {
+                f32x4 v = h_stage[it];
+                const bool k = (ok >> it) & 1u;
+                v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+                *reinterpret_cast<f32x4*>(sH + (idx >> 2) * PST + (idx & 3) * 4) = v;
+            }
+        }
+    };
+    // U layout in HBM: [chunk][ntile][16 freq][64 co][16 ci]
+    auto load_U = [&](int step) {          // step = chunk*4 + group
+        const float* src = a.w + ((long)((step >> 2) * a.grid_y + by) * 16 + (step & 3) * 4) * (64 * 16);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) u_stage[it] = *reinterpret_cast<const f32x4*>(src + (it * 256 + tid) * 4);
+    };
+    auto store_U = [&](int buf) {
+        float* dst = sU + buf * W_SU;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int idx = it * 256 + tid;
+            *reinterpret_cast<f32x4*>(dst + (idx >> 2) * PST + (idx & 3) * 4) = u_stage[it];
+        }
+    };
+    // input transform: thread = (tile, channel quad); V = B^T d B
+    const int t_tile = tid >> 2, t_q = tid & 3;
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    auto transform = [&]() {
+        const float* src = sH + ((2 * t_ty) * 18 + 2 * t_tx) * PST + t_q * 4;
+        f32x4 x[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {     // columns of the patch: apply B^T down the rows
+            f32x4 d0 = *reinterpret_cast<const f32x4*>(src + (0 * 18 + j) * PST);
+            f32x4 d1 = *reinterpret_cast<const f32x4*>(src + (1 * 18 + j) * PST);
+            f32x4 d2 = *reinterpret_cast<const f32x4*>(src + (2 * 18 + j) * PST);
+            f32x4 d3 = *reinterpret_cast<const f32x4*>(src + (3 * 18 + j) * PST);
+            x[0][j] = d0 - d2; x[1][j] = d1 + d2; x[2][j] = d2 - d1; x[3][j] = d1 - d3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v0 = x[i][0] - x[i][2], v1 = x[i][1] + x[i][2], v2 = x[i][2] - x[i][1], v3 = x[i][1] - x[i][3];
+            float* dst = sV + ((i * 4) * 64 + t_tile) * PST + t_q * 4;
+            *reinterpret_cast<f32x4*>(dst + 0 * 64 * PST) = v0;
+            *reinterpret_cast<f32x4*>(dst + 1 * 64 * PST) = v1;
+            *reinterpret_cast<f32x4*>(dst + 2 * 64 * PST) = v2;
+            *reinterpret_cast<f32x4*>(dst + 3 * 64 * PST) = v3;
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const float* Abase = sV + (mg * 32 + li) * PST + hh * 8;
+    const int b_off = (ng * 32 + li) * PST + hh * 8;
+
+    load_H(0);
+    load_U(0);
+    store_H();
+    store_U(0);
+    __syncthreads();
+    transform();
+
+    const int total_steps = nchunks * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const bool has_next_chunk = (c + 1 < nchunks);
+        if (has_next_chunk) load_H(c + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int step = c * 4 + g;
+            const bool has_next = (step + 1 < total_steps);
+            if (has_next) load_U(step + 1);
+            __syncthreads();          // V (g == 0) and U[g & 1] visible; everyone is done with the previous step
+            const float* B = sU + (g & 1) * W_SU + b_off;
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl) {
+                const int f = g * 4 + fl;
+                f32x4 a0 = *reinterpret_cast<const f32x4*>(Abase + f * 64 * PST);
+                f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + f * 64 * PST + 4);
+                f32x4 b0 = *reinterpret_cast<const f32x4*>(B + fl * 64 * PST);
+                f32x4 b1 = *reinterpret_cast<const f32x4*>(B + fl * 64 * PST + 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[f], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[f], 0, 0, 0);
+            }
+            if (has_next) store_U((g + 1) & 1);
+        }
+        if (has_next_chunk) {
+            __syncthreads();          // every wave is done reading V of this chunk (and the halo was consumed before)
+            store_H();
+            __syncthreads();
+            transform();
+        }
+    }
+
+    // ---- output transform (per lane, registers only) + epilogue ------------------------------------------------------
+    const int co = co0 + ng * 32 + li;
+    const bool cvalid = co < a.Cout;
+    const float sc = cvalid ? P.scale[co] : 0.f;
+    const float sh = cvalid ? P.shift[co] : 0.f;
+    const bool do_relu = co < a.relu_upto;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int t = mg * 32 + row;
+        const int oh = oh0 + 2 * (t >> 3), ow = ow0 + 2 * (t & 7);
+        float s0[4], s1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {     // M A : combine the 4 columns of row i
+            float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r], m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
+            s0[i] = m0 + m1 + m2;
+            s1[i] = m1 - m2 - m3;
+        }
+        float y[2][2];
+        y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s1[0] + s1[1] + s1[2];
+        y[1][0] = s0[1] - s0[2] - s0[3]; y[1][1] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                if (cvalid && oh + dy < H && ow + dx < W) {
+                    float v = y[dy][dx] * sc + sh;
+                    if (do_relu) v = fmaxf(v, 0.f);
+                    P.y[(((long)n * H + oh + dy) * W + ow + dx) * a.y_cs + a.y_co + co] = v;
+                }
+            }
+    }
+}
+
+static int launch_wino(ConvArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
+        if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    int blocks = 0;
+    for (int i = 0; i < a.nprob; ++i) {
+        ConvProblem& p = a.p[i];
+        p.tile_begin = blocks;
+        p.tiles_h = cdiv(p.Ho, 16);
+        p.tiles_w = cdiv(p.Wo, 16);
+        blocks += p.N * p.tiles_h * p.tiles_w;
+    }
+    a.grid_y = cdiv(a.Cout, 64);
+    hipLaunchKernelGGL(conv_wino_kernel, dim3(blocks * a.grid_y), dim3(256), W_LDS_BYTES, st, a);
+    return check_launch("conv_wino");
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side: variant menu + cost model
 // ---------------------------------------------------------------------------------------------------------------
@@ -466,6 +688,12 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const int cout32 = (d->Cout + 31) / 32;
     const int taps = d->ksize * d->ksize;
     hipStream_t st = (hipStream_t)stream;
+    if (d->tune_wm == 3) {                             // Winograd F(2x2,3x3): 3x3 stride 1, no residual / input ReLU, U-packed weights
+        if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino)
+            return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
+        a.w = d->w_wino;
+        return launch_wino(a, st);
+    }
     Variant v;
     if (d->tune_wm || d->tune_sc || d->tune_wn) {      // the caller measured and picked a variant
         v = Variant{d->tune_wm, d->tune_sc, d->tune_wn};
@@ -491,6 +719,10 @@ extern "C" int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize) {
     return taps * nch * cmk_conv_cout_pad(Cout) * 16;
 }
 
+extern "C" int64_t cmk_wino_packed_floats(int Cout, int Cin) {
+    return (int64_t)((Cin + 15) / 16) * ((Cout + 63) / 64) * 16 * 64 * 16;
+}
+
 extern "C" int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream) {
     int rc = cmk::validate(d);
     if (rc) return rc;
@@ -506,7 +738,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
         if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
-            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn)
+            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino)
             return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
     }
     return run(descs, n, stream);

@@ -75,6 +75,23 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return wp
 
 
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
+    """(Cout,Cin,3,3) -> U = G g G^T packed [Cin/16][ceil(Cout/64)][16 freq][64 co][16 ci] for conv_wino_kernel
+    (transform in float64, rounded once to float32)."""
+    lib = _lib.load()
+    cout, cin = w.shape[0], w.shape[1]
+    u = torch.einsum("ik,ockl,jl->ocij", _WINO_G, w.detach().double().cpu(), _WINO_G).reshape(cout, cin, 16)
+    cin_pad, nt = (cin + 15) // 16 * 16, (cout + 63) // 64
+    up = torch.zeros((cin_pad, nt * 64, 16), dtype=torch.float64)
+    up[:cin, :cout] = u.permute(1, 0, 2)
+    up = up.reshape(cin_pad // 16, 16, nt, 64, 16).permute(0, 2, 4, 3, 1).contiguous().float()
+    assert up.numel() == lib.cmk_wino_packed_floats(cout, cin)
+    return up
+
+
 class PackedConv:
     """Device-resident packed weights + per-channel epilogue (scale, shift) of one conv / linear layer."""
 
@@ -86,6 +103,7 @@ class PackedConv:
         self.cin_pad = (self.cin + 15) // 16 * 16
         self.stride = stride
         self.w = pack_conv_weight(weight).to(device)
+        self.w_wino = pack_wino_weight(weight).to(device) if (self.k == 3 and stride == 1 and self.cin >= 16) else None
         self.scale = (torch.ones(self.cout) if scale is None else scale.detach().float().cpu()).contiguous().to(device)
         self.shift = (torch.zeros(self.cout) if shift is None else shift.detach().float().cpu()).contiguous().to(device)
 
@@ -102,6 +120,7 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
     n, h, w = x.nhw
     d.x, d.x_cs, d.x_co = x.t.data_ptr(), x.cs, x.co
     d.w = pc.w.data_ptr()
+    d.w_wino = pc.w_wino.data_ptr() if getattr(pc, "w_wino", None) is not None else None
     d.scale, d.shift = pc.scale.data_ptr(), pc.shift.data_ptr()
     if res is not None:
         d.res, d.res_cs, d.res_co = res.t.data_ptr(), res.cs, res.co
@@ -122,6 +141,7 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
 
 
 # ---- tile-variant autotuning (host side; the library itself stays stateless) -----------------------------------
+ALLOW_WINOGRAD = True     # let the tuner pick the Winograd F(2x2,3x3) kernel where it is faster (fp32, differs by rounding only)
 AUTOTUNE = False          # when True, the first call of every distinct conv problem times the variant menu (needs an idle, non-capturing stream)
 _TUNED = {}               # problem key -> (wm, sc, wn)
 
@@ -174,9 +194,12 @@ def _tune(descs, n, key) -> None:
         return lib.cmk_conv2d_nhwc_multi(descs, n, st) if n > 1 else lib.cmk_conv2d_nhwc(ctypes.byref(descs[0]), st)
 
     best, best_ms = (0, 0, 0), float("inf")
-    for wn in range(1, 8):
-        for wm in (1, 2):
-            for sc in (16, 32):
+    cands = [(wm, sc, wn) for wn in range(1, 8) for wm in (1, 2) for sc in (16, 32)]
+    if ALLOW_WINOGRAD:
+        cands.append((3, 16, 2))                  # fused Winograd F(2x2,3x3) (3x3 stride 1 without residual only)
+    for wm, sc, wn in cands:
+        for _once in (0,):
+            for _once2 in (0,):
                 for i in range(n):
                     descs[i].tune_wm, descs[i].tune_sc, descs[i].tune_wn = wm, sc, wn
                 if run() != 0:
@@ -430,6 +453,8 @@ def _kernel_name(taps, stride, tv) -> str:
     """The template instantiation rocprofv3 will report: conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>."""
     if not tv or tv == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
+    if tv[0] == 3:
+        return "cmk::conv_wino_kernel(cmk::ConvArgs)"
     wm, sc, wn = tv
     return "conv_igemm_kernel<{}, {}, {}, {}, {}>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
 

@@ -49,6 +49,10 @@ typedef struct {
      * tune_wn in 1..7 (32*tune_wn output channels per workgroup; must divide the padded Cout).  Results are bitwise
      * identical across variants (the K order per output does not depend on the tile). */
     int tune_wm; int tune_sc; int tune_wn;
+    /* tune_wm == 3 selects the fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual): same fp32 arithmetic on the
+     * matrix pipe with 2.25x fewer multiplies; results differ from the direct kernel by fp32 rounding only.  It needs the
+     * weights pre-transformed to U = G g G^T, packed [Cin/16][ceil(Cout/64)][16][64][16] (cmk_wino_packed_floats). */
+    const float* w_wino;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
 /* Same conv applied to up to 5 inputs of different H x W in ONE launch (the FCOS towers/predictors share their weights
@@ -58,6 +62,7 @@ int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* stream);
 /* number of floats of the packed layout for (Cout, Cin, k): taps * ceil(Cin/16) * cout_pad * 16 */
 int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize);
 int cmk_conv_cout_pad(int Cout);
+int64_t cmk_wino_packed_floats(int Cout, int Cin);
 
 /* ---- stem_1: 3x3 stride-2 conv on the NCHW 3-channel image (vovnet.py:409), BN-folded, ReLU, NHWC out -------- */
 int cmk_stem_conv_nchw3(const float* x, const float* w /* [27][Cout] */, const float* scale, const float* shift,

@@ -172,3 +172,25 @@ def test_conv_tile_variants_forced(dev, variant):
         "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CMK_CONV_VARIANT=variant), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("case", [(2, 37, 45, 64, 128), (1, 16, 16, 256, 256), (1, 25, 40, 224, 224), (2, 14, 14, 256, 80), (1, 100, 160, 32, 5)])
+def test_conv_winograd_variant(dev, case):
+    """Fused Winograd F(2x2,3x3) kernel (variant 3) against torch; fp32 rounding differences only."""
+    import ctypes
+    from centermask2_amd import _lib
+    n, h, w, cin, cout = case
+    x = _rand((n, cin, h, w), 81)
+    wt = _rand((cout, cin, 3, 3), 82, (2.0 / (cin * 9)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(83)) + 0.5
+    shift = _rand((cout,), 84, 0.1)
+    ref = F.relu(F.conv2d(x, wt, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    pc = ops.PackedConv(wt, scale, shift, dev)
+    xv = ops.as_view(x.to(dev))
+    y = View(torch.full((n, h, w, cout), -5.0, device=dev))
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], xv, pc, y, True, None, None, False, False)
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 3, 16, 2
+    _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "wino")
+    torch.cuda.synchronize()
+    _close(y.nchw(), ref)
