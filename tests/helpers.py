@@ -2,7 +2,8 @@ import os
 
 import torch
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_ROOT = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(GOLDEN_ROOT, "golden")
 
 
 def golden(name):
@@ -33,3 +34,10 @@ def build_gpu_model(conv_body="V-39-eSE", seed=0):
     model = build_model(cfg).eval()
     model.load_state_dict(sd)
     return model, sd
+
+
+def load_shipped_variant_table():
+    """The measured conv variant table bench.py uses (Winograd where it wins), so parity is checked on the same kernels."""
+    from centermask2_amd import ops
+    path = os.path.join(os.path.dirname(GOLDEN_ROOT), "centermask2_amd", "tuned", "mi355x_V-39-eSE_b8_800x1280.json")
+    return ops.load_tuned(path) if os.path.exists(path) else 0

@@ -59,6 +59,33 @@ def _probe_check(t_nchw, p, tol, what):
     close(flat.double().mean().float().reshape(1), p["mean"].reshape(1), tol, what + " mean")
 
 
+def test_end_to_end_800x1280_batch8_tuned_variants_match_oracle(dev, model):
+    """The benchmark configuration itself (8 x 3x800x1280 with the shipped variant table, i.e. the Winograd / N-split kernels
+    bench.py times) against the oracle: labels and ROI locations exact, masks within 1e-3."""
+    from centermask2_amd import ops, synthetic as S
+    from oracle import centermask_oracle as O
+    from .helpers import load_shipped_variant_table
+    n_loaded = load_shipped_variant_table()
+    try:
+        x = S.make_synthetic_images(8, 800, 1280, seed0=1234)
+        sizes = [(800, 1280)] * 8
+        out = model.inference_padded(x.to(dev), sizes)
+        torch.cuda.synchronize()
+        res = model.results_from_padded(out, sizes)
+        sd = S.make_synthetic_state_dict("V-39-eSE", 0)
+        for i in (0, 5):                         # two of the eight images on the CPU oracle (a few seconds each)
+            want = O.centermask_inference(sd, x[i:i + 1], sizes[:1])[0]
+            assert torch.equal(res[i].pred_classes.cpu(), want["classes"]), "labels differ"
+            assert torch.equal(res[i].locations.cpu(), want["locations"]), "ROI locations differ"
+            close(res[i].pred_boxes.tensor, want["boxes"], 2e-5, "boxes")
+            close(res[i].scores, want["scores"], 1e-4, "scores")
+            close(res[i].pred_masks, want["pred_masks"], 1e-3, "masks")
+            close(res[i].mask_scores, want["mask_scores"], 1e-3, "mask_scores")
+    finally:
+        ops._TUNED.clear()
+    assert n_loaded >= 0
+
+
 def test_end_to_end_800x1280_matches_reference(dev, model):
     """BASELINE config 1 shape: two 800x1280 images through backbone -> FCOS -> CenterROIHeads; compares with what the
     reference produced for the same seeded weights/images."""
