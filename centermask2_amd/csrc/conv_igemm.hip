@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
             const float* B = sU + (g & 1) * W_SU + b_off;
 #pragma unroll
             for (int fl = 0; fl < 4; ++fl) {
-                const int f = g * 4 + fl;
+                const int f = (fl >> 1) * 8 + g * 2 + (fl & 1);     // U is packed in this step order (shared with the 8-wave kernel)
                 f32x4 a0 = *reinterpret_cast<const f32x4*>(Abase + f * 64 * PST);
                 f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + f * 64 * PST + 4);
                 f32x4 b0 = *reinterpret_cast<const f32x4*>(B + fl * 64 * PST);
@@ -512,10 +512,213 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
     }
 }
 
-static int launch_wino(ConvArgs& a, hipStream_t st) {
+// 8-wave form of the Winograd kernel: same workgroup tile and LDS image, but two waves per SIMD, each owning 8 of the 16
+// frequency accumulators of its (32 tiles x 32 couts) sub-tile (fh = frequency half = rows {0,1} or {2,3} of the 4x4
+// frequency grid).  A wave's barrier / LDS-read / staging stalls now hide under its SIMD partner's MFMAs.  The two halves
+// exchange their partial output transforms through LDS once at the end; each half then stores one of the two output rows.
+__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sH = smem;
+    float* sV = smem + W_SH;
+    float* sU = smem + W_SH + W_SV;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, li = lane & 31;
+    const int fh = wave >> 2, mg = (wave >> 1) & 1, ng = wave & 1;
+
+    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
+    const ConvProblem& P = a.p[pi];
+    const int H = P.H, W = P.W;
+    const int tile = bx - P.tile_begin;
+    const int tw = tile % P.tiles_w;
+    const int t2 = tile / P.tiles_w;
+    const int th = t2 % P.tiles_h;
+    const int n = t2 / P.tiles_h;
+    const int oh0 = th * 16, ow0 = tw * 16;
+    const int co0 = by * 64;
+    const int nchunks = a.Cin >> 4;
+
+    constexpr int H_ITERS = (W_HALO * 4 + 511) / 512;
+    const float* xin = P.x + (long)n * H * W * a.x_cs + a.x_co;
+    long g_off[H_ITERS];
+    unsigned ok = 0;
+#pragma unroll
+    for (int it = 0; it < H_ITERS; ++it) {
+        int idx = it * 512 + tid;
+        int pix = idx >> 2, q = idx & 3;
+        long off = 0;
+        if (idx < W_HALO * 4) {
+            int hr = pix / 18, hc = pix - hr * 18;
+            int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) { off = ((long)ih * W + iw) * a.x_cs + q * 4; ok |= 1u << it; }
+        }
+        g_off[it] = off;
+    }
+    f32x4 h_stage[H_ITERS];
+    f32x4 u_stage[2];
+    auto load_H = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < H_ITERS; ++it) h_stage[it] = *reinterpret_cast<const f32x4*>(xin + g_off[it] + chunk * 16);
+    };
+    auto store_H = [&]() {
+#pragma unroll
+        for (int it = 0; it < H_ITERS; ++it) {
+            int idx = it * 512 + tid;
+            if ((it + 1) * 512 <= W_HALO * 4 || idx < W_HALO * 4) {
+                f32x4 v = h_stage[it];
+                const bool k = (ok >> it) & 1u;
+                v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+                *reinterpret_cast<f32x4*>(sH + (idx >> 2) * PST + (idx & 3) * 4) = v;
+            }
+        }
+    };
+    auto load_U = [&](int step) {
+        const float* src = a.w + ((long)((step >> 2) * a.grid_y + by) * 16 + (step & 3) * 4) * (64 * 16);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) u_stage[it] = *reinterpret_cast<const f32x4*>(src + (it * 512 + tid) * 4);
+    };
+    auto store_U = [&](int buf) {
+        float* dst = sU + buf * W_SU;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            int idx = it * 512 + tid;
+            *reinterpret_cast<f32x4*>(dst + (idx >> 2) * PST + (idx & 3) * 4) = u_stage[it];
+        }
+    };
+    // input transform split over the two thread halves: half h2 produces frequency rows {2*h2, 2*h2+1}
+    const int t_half = tid >> 8, t_tile = (tid >> 2) & 63, t_q = tid & 3;
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    auto transform = [&]() {
+        const float* src = sH + ((2 * t_ty + t_half) * 18 + 2 * t_tx) * PST + t_q * 4;   // patch rows t_half .. t_half+2
+        f32x4 x0[4], x1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 da = *reinterpret_cast<const f32x4*>(src + (0 * 18 + j) * PST);
+            f32x4 db = *reinterpret_cast<const f32x4*>(src + (1 * 18 + j) * PST);
+            f32x4 dc = *reinterpret_cast<const f32x4*>(src + (2 * 18 + j) * PST);
+            if (t_half == 0) { x0[j] = da - dc; x1[j] = db + dc; }        // rows 0,1 of B^T d from d0,d1,d2
+            else             { x0[j] = db - da; x1[j] = da - dc; }        // rows 2,3 of B^T d from d1,d2,d3 (da=d1, db=d2, dc=d3)
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const f32x4* x = ii == 0 ? x0 : x1;
+            f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
+            float* dst = sV + (((2 * t_half + ii) * 4) * 64 + t_tile) * PST + t_q * 4;
+            *reinterpret_cast<f32x4*>(dst + 0 * 64 * PST) = v0;
+            *reinterpret_cast<f32x4*>(dst + 1 * 64 * PST) = v1;
+            *reinterpret_cast<f32x4*>(dst + 2 * 64 * PST) = v2;
+            *reinterpret_cast<f32x4*>(dst + 3 * 64 * PST) = v3;
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const float* Abase = sV + ((fh * 8) * 64 + mg * 32 + li) * PST + hh * 8;
+    const int b_off = ((fh * 2) * 64 + ng * 32 + li) * PST + hh * 8;
+
+    load_H(0);
+    load_U(0);
+    store_H();
+    store_U(0);
+    __syncthreads();
+    transform();
+
+    const int total_steps = nchunks * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const bool has_next_chunk = (c + 1 < nchunks);
+        if (has_next_chunk) load_H(c + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int step = c * 4 + g;
+            const bool has_next = (step + 1 < total_steps);
+            if (has_next) load_U(step + 1);
+            __syncthreads();
+            const float* B = sU + (g & 1) * W_SU + b_off;
+#pragma unroll
+            for (int fl = 0; fl < 2; ++fl) {
+                const int al = g * 2 + fl;            // local accumulator = frequency fh*8 + al
+                f32x4 a0 = *reinterpret_cast<const f32x4*>(Abase + al * 64 * PST);
+                f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + al * 64 * PST + 4);
+                f32x4 b0 = *reinterpret_cast<const f32x4*>(B + fl * 64 * PST);
+                f32x4 b1 = *reinterpret_cast<const f32x4*>(B + fl * 64 * PST + 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[al], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[al], 0, 0, 0);
+            }
+            if (has_next) store_U((g + 1) & 1);
+        }
+        if (has_next_chunk) {
+            __syncthreads();
+            store_H();
+            __syncthreads();
+            transform();
+        }
+    }
+
+    // ---- output transform: own half in registers, partner's half through LDS ----------------------------------------------
+    __syncthreads();                       // every wave is done with sV; reuse it for the exchange
+    float* ex = sV;                        // [wave 8][r 16][2][64 lanes]
+    float keep[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s0[2], s1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {      // my two frequency rows: accumulators i*4 .. i*4+3
+            float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r], m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
+            s0[i] = m0 + m1 + m2;
+            s1[i] = m1 - m2 - m3;
+        }
+        float send0, send1;
+        if (fh == 0) {                     // rows 0,1: Y0 += s[0]+s[1] (kept), Y1 += s[1] (sent)
+            keep[r][0] = s0[0] + s0[1]; keep[r][1] = s1[0] + s1[1];
+            send0 = s0[1]; send1 = s1[1];
+        } else {                           // rows 2,3: Y0 += s[2] (sent), Y1 += -s[2]-s[3] (kept)
+            keep[r][0] = -s0[0] - s0[1]; keep[r][1] = -s1[0] - s1[1];
+            send0 = s0[0]; send1 = s1[0];
+        }
+        ex[((wave * 16 + r) * 2 + 0) * 64 + lane] = send0;
+        ex[((wave * 16 + r) * 2 + 1) * 64 + lane] = send1;
+    }
+    __syncthreads();
+    const int partner = wave ^ 4;
+    const int co = co0 + ng * 32 + li;
+    const bool cvalid = co < a.Cout;
+    const float sc = cvalid ? P.scale[co] : 0.f;
+    const float sh = cvalid ? P.shift[co] : 0.f;
+    const bool do_relu = co < a.relu_upto;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int t = mg * 32 + row;
+        const int oh = oh0 + 2 * (t >> 3) + fh, ow = ow0 + 2 * (t & 7);      // half 0 stores output row 0, half 1 row 1
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            float yv = keep[r][dx] + ex[((partner * 16 + r) * 2 + dx) * 64 + lane];
+            if (cvalid && oh < H && ow + dx < W) {
+                float v = yv * sc + sh;
+                if (do_relu) v = fmaxf(v, 0.f);
+                P.y[(((long)n * H + oh) * W + ow + dx) * a.y_cs + a.y_co + co] = v;
+            }
+        }
+    }
+}
+
+static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
         if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -528,7 +731,10 @@ static int launch_wino(ConvArgs& a, hipStream_t st) {
         blocks += p.N * p.tiles_h * p.tiles_w;
     }
     a.grid_y = cdiv(a.Cout, 64);
-    hipLaunchKernelGGL(conv_wino_kernel, dim3(blocks * a.grid_y), dim3(256), W_LDS_BYTES, st, a);
+    if (waves8)
+        hipLaunchKernelGGL(conv_wino8_kernel, dim3(blocks * a.grid_y), dim3(512), W_LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL(conv_wino_kernel, dim3(blocks * a.grid_y), dim3(256), W_LDS_BYTES, st, a);
     return check_launch("conv_wino");
 }
 
@@ -688,11 +894,11 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const int cout32 = (d->Cout + 31) / 32;
     const int taps = d->ksize * d->ksize;
     hipStream_t st = (hipStream_t)stream;
-    if (d->tune_wm == 3) {                             // Winograd F(2x2,3x3): 3x3 stride 1, no residual / input ReLU, U-packed weights
+    if (d->tune_wm == 3 || d->tune_wm == 4) {          // Winograd F(2x2,3x3) (3 = 4 waves, 4 = 8 waves): 3x3 stride 1, no residual / input ReLU
         if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino)
             return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
         a.w = d->w_wino;
-        return launch_wino(a, st);
+        return launch_wino(a, d->tune_wm == 4, st);
     }
     Variant v;
     if (d->tune_wm || d->tune_sc || d->tune_wn) {      // the caller measured and picked a variant

@@ -174,8 +174,9 @@ def test_conv_tile_variants_forced(dev, variant):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("waves", [3, 4])
 @pytest.mark.parametrize("case", [(2, 37, 45, 64, 128), (1, 16, 16, 256, 256), (1, 25, 40, 224, 224), (2, 14, 14, 256, 80), (1, 100, 160, 32, 5)])
-def test_conv_winograd_variant(dev, case):
+def test_conv_winograd_variant(dev, case, waves):
     """Fused Winograd F(2x2,3x3) kernel (variant 3) against torch; fp32 rounding differences only."""
     import ctypes
     from centermask2_amd import _lib
@@ -190,7 +191,7 @@ def test_conv_winograd_variant(dev, case):
     y = View(torch.full((n, h, w, cout), -5.0, device=dev))
     d = (_lib.ConvDesc * 1)()
     ops._fill_desc(d[0], xv, pc, y, True, None, None, False, False)
-    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 3, 16, 2
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = waves, 16, 2
     _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "wino")
     torch.cuda.synchronize()
     _close(y.nchw(), ref)
