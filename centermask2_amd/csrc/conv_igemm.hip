@@ -401,7 +401,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             int idx = it * 256 + tid;
-            *reinterpret_cast<f32x4*>(dst + (idx >> 2) * PST + (idx & 3) * 4) = u_stage[it];
+            int row = idx >> 2;           // HBM holds the swizzled image: physical chunk p carries logical chunk p ^ ((co>>2)&3)
+            *reinterpret_cast<f32x4*>(dst + row * PST + ((idx & 3) ^ ((row >> 2) & 3)) * 4) = u_stage[it];
         }
     };
     // input transform: thread = (tile, channel quad); V = B^T d B
@@ -587,7 +588,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             int idx = it * 512 + tid;
-            *reinterpret_cast<f32x4*>(dst + (idx >> 2) * PST + (idx & 3) * 4) = u_stage[it];
+            int row = idx >> 2;
+            *reinterpret_cast<f32x4*>(dst + row * PST + ((idx & 3) ^ ((row >> 2) & 3)) * 4) = u_stage[it];
         }
     };
     // input transform split over the two thread halves: half h2 produces frequency rows {2*h2, 2*h2+1}
@@ -713,12 +715,201 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvArgs a) {
     }
 }
 
+
+// Third form: the halo tile is not staged at all.  Every thread fetches its 3x4 input patch (the rows its half of the
+// input transform needs) straight from global memory/L1 into registers one chunk ahead, transforms it in registers and
+// writes only V to LDS.  The weights go HBM -> LDS directly (global_load_lds, no VGPR staging, 8 frequencies per step):
+// the packed U image in HBM is already the LDS image (64-byte rows, 16-byte chunks XOR-swizzled by (co>>2)&3 so that the
+// ds_read_b128 operand reads are conflict-free without padding).  A chunk costs 3 barriers (2 steps + 1 hand-over).
+constexpr int W2_SU = 8 * 64 * 16;                           // floats per step: 8 frequencies, unpadded
+constexpr int W2_LDS_BYTES = (W_SV + 2 * W2_SU) * 4;         // 80 KiB + 64 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__global__ __launch_bounds__(512, 2) void conv_wino8b_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sV = smem;
+    float* sU = smem + W_SV;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, li = lane & 31;
+    const int fh = wave >> 2, mg = (wave >> 1) & 1, ng = wave & 1;
+
+    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
+    const ConvProblem& P = a.p[pi];
+    const int H = P.H, W = P.W;
+    const int tile = bx - P.tile_begin;
+    const int tw = tile % P.tiles_w;
+    const int t2 = tile / P.tiles_w;
+    const int th = t2 % P.tiles_h;
+    const int n = t2 / P.tiles_h;
+    const int oh0 = th * 16, ow0 = tw * 16;
+    const int co0 = by * 64;
+    const int nchunks = a.Cin >> 4;
+
+    // my patch: rows (2*ty + half) .. +2, cols 2*tx .. +3 of the halo frame (origin oh0-1, ow0-1), channel quad q
+    const int t_half = tid >> 8, t_tile = (tid >> 2) & 63, t_q = tid & 3;
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    const float* xin = P.x + (long)n * H * W * a.x_cs + a.x_co + t_q * 4;
+    // addresses are row offset + column offset with each coordinate clamped into the image (always a valid address);
+    // `ok` remembers which of the 12 elements are real, the others are zero padding
+    int row_off[3], col_off[4];
+    unsigned ok = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int ih = oh0 - 1 + 2 * t_ty + t_half + r;
+        row_off[r] = min(max(ih, 0), H - 1) * W * a.x_cs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int iw = ow0 - 1 + 2 * t_tx + j;
+            ok |= ((ih >= 0 && ih < H && iw >= 0 && iw < W) ? 1u : 0u) << (r * 4 + j);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) col_off[j] = min(max(ow0 - 1 + 2 * t_tx + j, 0), W - 1) * a.x_cs;
+    f32x4 patch[12];
+    auto load_P = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) patch[k] = *reinterpret_cast<const f32x4*>(xin + row_off[k >> 2] + col_off[k & 3] + chunk * 16);
+    };
+    // step = chunk*2 + half-of-frequencies; its U image (8 freq x 64 co x 16 ci, 32 KiB) is contiguous in HBM
+    auto glds_U = [&](int step, int buf) {
+        const float* src = a.w + ((long)((step >> 1) * a.grid_y + by) * 16 + (step & 1) * 8) * (64 * 16);
+        float* dst = sU + buf * W2_SU;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)     // one wave-instruction = 1 KiB: LDS dest = wave-uniform base + lane*16
+            __builtin_amdgcn_global_load_lds(src + (it * 512 + tid) * 4, (lds_void*)(dst + (it * 512 + wave * 64) * 4), 16, 0, 0);
+    };
+    auto transform = [&]() {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 x0[4], x1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 da = ((ok >> (0 + j)) & 1u) ? patch[0 + j] : z;
+            f32x4 db = ((ok >> (4 + j)) & 1u) ? patch[4 + j] : z;
+            f32x4 dc = ((ok >> (8 + j)) & 1u) ? patch[8 + j] : z;
+            if (t_half == 0) { x0[j] = da - dc; x1[j] = db + dc; }
+            else             { x0[j] = db - da; x1[j] = da - dc; }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const f32x4* x = ii == 0 ? x0 : x1;
+            f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
+            float* dst = sV + (((2 * t_half + ii) * 4) * 64 + t_tile) * PST + t_q * 4;
+            *reinterpret_cast<f32x4*>(dst + 0 * 64 * PST) = v0;
+            *reinterpret_cast<f32x4*>(dst + 1 * 64 * PST) = v1;
+            *reinterpret_cast<f32x4*>(dst + 2 * 64 * PST) = v2;
+            *reinterpret_cast<f32x4*>(dst + 3 * 64 * PST) = v3;
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const float* Abase = sV + ((fh * 8) * 64 + mg * 32 + li) * PST + hh * 8;
+    const int sw = (li >> 2) & 3;                                         // chunk swizzle of row co = ng*32 + li
+    const int b_row = ((fh * 2) * 64 + ng * 32 + li) * 16;
+    const int b_c0 = ((2 * hh) ^ sw) * 4, b_c1 = ((2 * hh + 1) ^ sw) * 4;
+
+    load_P(0);
+    glds_U(0, 0);
+    transform();
+
+    const int total_steps = nchunks * 2;
+    for (int c = 0; c < nchunks; ++c) {
+        const bool has_next_chunk = (c + 1 < nchunks);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int step = c * 2 + st;
+            __syncthreads();          // V (st == 0) and U[st] landed and visible; everyone is done with the previous step
+            if (step + 1 < total_steps) glds_U(step + 1, st ^ 1);          // in flight during this step's MFMAs
+            if (st == 0 && has_next_chunk) load_P(c + 1);
+            const float* B = sU + st * W2_SU + b_row;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl) {
+                    const int al = (st * 2 + gg) * 2 + fl;        // local accumulator = frequency fh*8 + al
+                    f32x4 a0 = *reinterpret_cast<const f32x4*>(Abase + al * 64 * PST);
+                    f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + al * 64 * PST + 4);
+                    f32x4 b0 = *reinterpret_cast<const f32x4*>(B + (gg * 4 + fl) * 64 * 16 + b_c0);
+                    f32x4 b1 = *reinterpret_cast<const f32x4*>(B + (gg * 4 + fl) * 64 * 16 + b_c1);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[al], 0, 0, 0);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[al], 0, 0, 0);
+                }
+        }
+        if (has_next_chunk) {
+            __syncthreads();          // every wave is done reading V of this chunk
+            transform();
+        }
+    }
+
+    // ---- output transform: own half in registers, partner's half through LDS (as in conv_wino8_kernel) ------------------
+    __syncthreads();
+    float* ex = sV;
+    float keep[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s0[2], s1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r], m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
+            s0[i] = m0 + m1 + m2;
+            s1[i] = m1 - m2 - m3;
+        }
+        float send0, send1;
+        if (fh == 0) {
+            keep[r][0] = s0[0] + s0[1]; keep[r][1] = s1[0] + s1[1];
+            send0 = s0[1]; send1 = s1[1];
+        } else {
+            keep[r][0] = -s0[0] - s0[1]; keep[r][1] = -s1[0] - s1[1];
+            send0 = s0[0]; send1 = s1[0];
+        }
+        ex[((wave * 16 + r) * 2 + 0) * 64 + lane] = send0;
+        ex[((wave * 16 + r) * 2 + 1) * 64 + lane] = send1;
+    }
+    __syncthreads();
+    const int partner = wave ^ 4;
+    const int co = co0 + ng * 32 + li;
+    const bool cvalid = co < a.Cout;
+    const float sc = cvalid ? P.scale[co] : 0.f;
+    const float sh = cvalid ? P.shift[co] : 0.f;
+    const bool do_relu = co < a.relu_upto;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int t = mg * 32 + row;
+        const int oh = oh0 + 2 * (t >> 3) + fh, ow = ow0 + 2 * (t & 7);
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            float yv = keep[r][dx] + ex[((partner * 16 + r) * 2 + dx) * 64 + lane];
+            if (cvalid && oh < H && ow + dx < W) {
+                float v = yv * sc + sh;
+                if (do_relu) v = fmaxf(v, 0.f);
+                P.y[(((long)n * H + oh) * W + ow + dx) * a.y_cs + a.y_co + co] = v;
+            }
+        }
+    }
+}
+
 static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
         if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -731,7 +922,9 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
         blocks += p.N * p.tiles_h * p.tiles_w;
     }
     a.grid_y = cdiv(a.Cout, 64);
-    if (waves8)
+    if (waves8 == 2)
+        hipLaunchKernelGGL(conv_wino8b_kernel, dim3(blocks * a.grid_y), dim3(512), W2_LDS_BYTES, st, a);
+    else if (waves8)
         hipLaunchKernelGGL(conv_wino8_kernel, dim3(blocks * a.grid_y), dim3(512), W_LDS_BYTES, st, a);
     else
         hipLaunchKernelGGL(conv_wino_kernel, dim3(blocks * a.grid_y), dim3(256), W_LDS_BYTES, st, a);
@@ -894,11 +1087,12 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const int cout32 = (d->Cout + 31) / 32;
     const int taps = d->ksize * d->ksize;
     hipStream_t st = (hipStream_t)stream;
-    if (d->tune_wm == 3 || d->tune_wm == 4) {          // Winograd F(2x2,3x3) (3 = 4 waves, 4 = 8 waves): 3x3 stride 1, no residual / input ReLU
+    if (d->tune_wm >= 3 && d->tune_wm <= 5) {          // Winograd F(2x2,3x3) (3 = 4 waves, 4 = 8 waves, 5 = 8 waves with register-staged patches): 3x3 stride 1, no residual / input ReLU
         if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino)
             return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
         a.w = d->w_wino;
-        return launch_wino(a, d->tune_wm == 4, st);
+        if (d->tune_wm == 5 && (long)d->H * d->W * d->x_cs >= (1L << 31)) return fail(CMK_EINVAL, "conv: image too large for 32-bit patch offsets%s", "");
+        return launch_wino(a, d->tune_wm - 3, st);
     }
     Variant v;
     if (d->tune_wm || d->tune_sc || d->tune_wn) {      // the caller measured and picked a variant

@@ -89,7 +89,13 @@ def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
     up[:cin, :cout] = u.permute(1, 0, 2)
     order = [f for g in range(4) for f in (2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g)]      # the kernels' streaming order
     up = up[:, :, order]
-    up = up.reshape(cin_pad // 16, 16, nt, 64, 16).permute(0, 2, 4, 3, 1).contiguous().float()
+    up = up.reshape(cin_pad // 16, 16, nt, 64, 16).permute(0, 2, 4, 3, 1).contiguous().float()      # [chunk][ntile][freq][co][16 ci]
+    # the HBM image is the LDS image: 16-byte chunk p of row co holds logical chunk p ^ ((co >> 2) & 3)  (bank-conflict-free
+    # ds_read_b128 without padding; global_load_lds copies it verbatim)
+    co = torch.arange(64)
+    src_chunk = torch.arange(4)[None, :] ^ ((co[:, None] >> 2) & 3)                                      # [co][p] -> logical chunk
+    up = up.reshape(cin_pad // 16, nt, 16, 64, 4, 4)
+    up = torch.gather(up, 4, src_chunk[None, None, None, :, :, None].expand(cin_pad // 16, nt, 16, 64, 4, 4)).reshape(cin_pad // 16, nt, 16, 64, 16).contiguous()
     assert up.numel() == lib.cmk_wino_packed_floats(cout, cin)
     return up
 
@@ -198,7 +204,7 @@ def _tune(descs, n, key) -> None:
     best, best_ms = (0, 0, 0), float("inf")
     cands = [(wm, sc, wn) for wn in range(1, 8) for wm in (1, 2) for sc in (16, 32)]
     if ALLOW_WINOGRAD:
-        cands += [(3, 16, 2), (4, 16, 2)]         # fused Winograd F(2x2,3x3), 4- and 8-wave forms (3x3 stride 1 without residual only)
+        cands += [(3, 16, 2), (4, 16, 2), (5, 16, 2)]         # fused Winograd F(2x2,3x3), 4- and 8-wave forms (3x3 stride 1 without residual only)
     for wm, sc, wn in cands:
         for _once in (0,):
             for _once2 in (0,):
@@ -455,8 +461,8 @@ def _kernel_name(taps, stride, tv) -> str:
     """The template instantiation rocprofv3 will report: conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>."""
     if not tv or tv == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
-    if tv[0] in (3, 4):
-        return "cmk::conv_wino_kernel(cmk::ConvArgs)" if tv[0] == 3 else "cmk::conv_wino8_kernel(cmk::ConvArgs)"
+    if tv[0] in (3, 4, 5):
+        return "cmk::conv_wino{}_kernel(cmk::ConvArgs)".format({3: "", 4: "8", 5: "8b"}[tv[0]])
     wm, sc, wn = tv
     return "conv_igemm_kernel<{}, {}, {}, {}, {}>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
 

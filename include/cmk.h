@@ -52,7 +52,8 @@ typedef struct {
     /* tune_wm == 3 (4 waves) or 4 (8 waves) selects the fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual): same fp32 arithmetic on the
      * matrix pipe with 2.25x fewer multiplies; results differ from the direct kernel by fp32 rounding only.  It needs the
      * weights pre-transformed to U = G g G^T, packed [Cin/16][ceil(Cout/64)][16 freq in step order][64][16] (cmk_wino_packed_floats);
-     * step g streams the frequencies {2g, 2g+1, 8+2g, 9+2g} of the row-major 4x4 frequency grid. */
+     * step g streams the frequencies {2g, 2g+1, 8+2g, 9+2g} of the row-major 4x4 frequency grid; within a 64-byte row
+     * (one co, 16 ci) the 16-byte chunk at position p holds logical chunk p ^ ((co >> 2) & 3) (the LDS swizzle). */
     const float* w_wino;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
