@@ -902,6 +902,204 @@ __global__ __launch_bounds__(512, 2) void conv_wino8b_kernel(const ConvArgs a) {
     }
 }
 
+// Fourth form, built for residency: a 4-wave workgroup covers 8x16 output pixels (32 tiles) x 64 couts, the two frequency
+// halves and the two cout halves being the four waves.  With V and U kept unpadded (XOR-swizzled 64-byte rows) the LDS
+// image is 78 KiB, so TWO workgroups live on a CU: while one is in its staging/transform phase the other one's MFMAs keep
+// the matrix pipe busy (the measured loss of the 8-wave forms is exactly that phase: all waves of the only resident
+// workgroup transform at the same time and the pipe idles).  Weights arrive by global_load_lds.
+constexpr int S_HALO = 10 * 18;
+constexpr int S_SH = S_HALO * PST;                 // floats
+constexpr int S_SV = 16 * 32 * 16;
+constexpr int S_SU = 4 * 64 * 16;                  // one step = 4 frequencies
+constexpr int S_LDS_BYTES = (S_SH + S_SV + 2 * S_SU) * 4;
+constexpr int S_H_ITERS = (S_HALO * 4 + 255) / 256;
+
+__global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sH = smem;
+    float* sV = smem + S_SH;
+    float* sU = smem + S_SH + S_SV;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, li = lane & 31;
+    const int fh = wave >> 1, ng = wave & 1;
+
+    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
+    const ConvProblem& P = a.p[pi];
+    const int H = P.H, W = P.W;
+    const int tile = bx - P.tile_begin;
+    const int tw = tile % P.tiles_w;
+    const int t2 = tile / P.tiles_w;
+    const int th = t2 % P.tiles_h;
+    const int n = t2 / P.tiles_h;
+    const int oh0 = th * 8, ow0 = tw * 16;
+    const int co0 = by * 64;
+    const int nchunks = a.Cin >> 4;
+
+    const float* xin = P.x + (long)n * H * W * a.x_cs + a.x_co;
+    long g_off[S_H_ITERS];
+    unsigned ok = 0;
+#pragma unroll
+    for (int it = 0; it < S_H_ITERS; ++it) {
+        int idx = it * 256 + tid;
+        int pix = idx >> 2, q = idx & 3;
+        long off = 0;
+        if (idx < S_HALO * 4) {
+            int hr = pix / 18, hc = pix - hr * 18;
+            int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) { off = ((long)ih * W + iw) * a.x_cs + q * 4; ok |= 1u << it; }
+        }
+        g_off[it] = off;
+    }
+    f32x4 h_stage[S_H_ITERS];
+    auto load_H = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < S_H_ITERS; ++it) h_stage[it] = *reinterpret_cast<const f32x4*>(xin + g_off[it] + chunk * 16);
+    };
+    auto store_H = [&]() {
+#pragma unroll
+        for (int it = 0; it < S_H_ITERS; ++it) {
+            int idx = it * 256 + tid;
+            if ((it + 1) * 256 <= S_HALO * 4 || idx < S_HALO * 4) {
+                f32x4 v = h_stage[it];
+                const bool k = (ok >> it) & 1u;
+                v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+                *reinterpret_cast<f32x4*>(sH + (idx >> 2) * PST + (idx & 3) * 4) = v;
+            }
+        }
+    };
+    auto glds_U = [&](int step, int buf) {          // step = chunk*4 + group; 4 freq x 64 co x 16 ci = 16 KiB contiguous
+        const float* src = a.w + ((long)((step >> 2) * a.grid_y + by) * 16 + (step & 3) * 4) * (64 * 16);
+        float* dst = sU + buf * S_SU;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            __builtin_amdgcn_global_load_lds(src + (it * 256 + tid) * 4, (lds_void*)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
+    };
+    const int t_half = tid >> 7, t_tile = (tid >> 2) & 31, t_q = tid & 3;
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    const int v_chunk = (t_q ^ ((t_tile >> 2) & 3)) * 4;
+    auto transform = [&]() {
+        const float* src = sH + ((2 * t_ty + t_half) * 18 + 2 * t_tx) * PST + t_q * 4;
+        f32x4 x0[4], x1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 da = *reinterpret_cast<const f32x4*>(src + (0 * 18 + j) * PST);
+            f32x4 db = *reinterpret_cast<const f32x4*>(src + (1 * 18 + j) * PST);
+            f32x4 dc = *reinterpret_cast<const f32x4*>(src + (2 * 18 + j) * PST);
+            if (t_half == 0) { x0[j] = da - dc; x1[j] = db + dc; }
+            else             { x0[j] = db - da; x1[j] = da - dc; }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const f32x4* x = ii == 0 ? x0 : x1;
+            f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
+            float* dst = sV + (((2 * t_half + ii) * 4) * 32 + t_tile) * 16 + v_chunk;
+            *reinterpret_cast<f32x4*>(dst + 0 * 32 * 16) = v0;
+            *reinterpret_cast<f32x4*>(dst + 1 * 32 * 16) = v1;
+            *reinterpret_cast<f32x4*>(dst + 2 * 32 * 16) = v2;
+            *reinterpret_cast<f32x4*>(dst + 3 * 32 * 16) = v3;
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    const int c0 = ((2 * hh) ^ sw) * 4, c1 = ((2 * hh + 1) ^ sw) * 4;
+    const float* Abase = sV + ((fh * 8) * 32 + li) * 16;
+    const int b_row = ((fh * 2) * 64 + ng * 32 + li) * 16;
+
+    load_H(0);
+    glds_U(0, 0);
+    store_H();
+    __syncthreads();
+    transform();
+
+    const int total_steps = nchunks * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const bool has_next_chunk = (c + 1 < nchunks);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int step = c * 4 + g;
+            __syncthreads();          // V (g == 0) and U[g & 1] landed and visible; everyone is done with the previous step
+            if (step + 1 < total_steps) glds_U(step + 1, (g + 1) & 1);
+            if (g == 0 && has_next_chunk) load_H(c + 1);
+            const float* B = sU + (g & 1) * S_SU + b_row;
+#pragma unroll
+            for (int fl = 0; fl < 2; ++fl) {
+                const int al = g * 2 + fl;
+                f32x4 a0 = *reinterpret_cast<const f32x4*>(Abase + al * 32 * 16 + c0);
+                f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + al * 32 * 16 + c1);
+                f32x4 b0 = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c0);
+                f32x4 b1 = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[al], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[al], 0, 0, 0);
+            }
+        }
+        if (has_next_chunk) {
+            __syncthreads();          // every wave is done reading V (and the halo was consumed by the last transform)
+            store_H();
+            __syncthreads();
+            transform();
+        }
+    }
+
+    __syncthreads();
+    float* ex = sV;                        // [wave 4][r 16][2][64 lanes] = 32 KiB
+    float keep[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s0[2], s1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r], m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
+            s0[i] = m0 + m1 + m2;
+            s1[i] = m1 - m2 - m3;
+        }
+        float send0, send1;
+        if (fh == 0) {
+            keep[r][0] = s0[0] + s0[1]; keep[r][1] = s1[0] + s1[1];
+            send0 = s0[1]; send1 = s1[1];
+        } else {
+            keep[r][0] = -s0[0] - s0[1]; keep[r][1] = -s1[0] - s1[1];
+            send0 = s0[0]; send1 = s1[0];
+        }
+        ex[((wave * 16 + r) * 2 + 0) * 64 + lane] = send0;
+        ex[((wave * 16 + r) * 2 + 1) * 64 + lane] = send1;
+    }
+    __syncthreads();
+    const int partner = wave ^ 2;
+    const int co = co0 + ng * 32 + li;
+    const bool cvalid = co < a.Cout;
+    const float sc = cvalid ? P.scale[co] : 0.f;
+    const float sh = cvalid ? P.shift[co] : 0.f;
+    const bool do_relu = co < a.relu_upto;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = (r & 3) + 8 * (r >> 2) + 4 * hh;        // tile index 0..31 (4 tile rows x 8 tile cols)
+        const int oh = oh0 + 2 * (t >> 3) + fh, ow = ow0 + 2 * (t & 7);
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            float yv = keep[r][dx] + ex[((partner * 16 + r) * 2 + dx) * 64 + lane];
+            if (cvalid && oh < H && ow + dx < W) {
+                float v = yv * sc + sh;
+                if (do_relu) v = fmaxf(v, 0.f);
+                P.y[(((long)n * H + oh) * W + ow + dx) * a.y_cs + a.y_co + co] = v;
+            }
+        }
+    }
+}
+
 static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -910,6 +1108,8 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
         if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -917,12 +1117,14 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     for (int i = 0; i < a.nprob; ++i) {
         ConvProblem& p = a.p[i];
         p.tile_begin = blocks;
-        p.tiles_h = cdiv(p.Ho, 16);
+        p.tiles_h = cdiv(p.Ho, waves8 == 3 ? 8 : 16);
         p.tiles_w = cdiv(p.Wo, 16);
         blocks += p.N * p.tiles_h * p.tiles_w;
     }
     a.grid_y = cdiv(a.Cout, 64);
-    if (waves8 == 2)
+    if (waves8 == 3)
+        hipLaunchKernelGGL(conv_wino4s_kernel, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a);
+    else if (waves8 == 2)
         hipLaunchKernelGGL(conv_wino8b_kernel, dim3(blocks * a.grid_y), dim3(512), W2_LDS_BYTES, st, a);
     else if (waves8)
         hipLaunchKernelGGL(conv_wino8_kernel, dim3(blocks * a.grid_y), dim3(512), W_LDS_BYTES, st, a);
@@ -1087,7 +1289,7 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const int cout32 = (d->Cout + 31) / 32;
     const int taps = d->ksize * d->ksize;
     hipStream_t st = (hipStream_t)stream;
-    if (d->tune_wm >= 3 && d->tune_wm <= 5) {          // Winograd F(2x2,3x3) (3 = 4 waves, 4 = 8 waves, 5 = 8 waves with register-staged patches): 3x3 stride 1, no residual / input ReLU
+    if (d->tune_wm >= 3 && d->tune_wm <= 6) {          // Winograd F(2x2,3x3) (3 = 4 waves, 4 = 8 waves, 5 = 8 waves with register-staged patches, 6 = 4 waves x 2 workgroups per CU): 3x3 stride 1, no residual / input ReLU
         if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino)
             return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
         a.w = d->w_wino;
