@@ -462,7 +462,7 @@ def _kernel_name(taps, stride, tv) -> str:
     if not tv or tv == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
     if tv[0] in (3, 4, 5, 6):
-        return "cmk::conv_wino{}_kernel(cmk::ConvArgs)".format({3: "", 4: "8", 5: "8b", 6: "4s"}[tv[0]])
+        return "cmk::conv_wino{}_kernel".format({3: "", 4: "8", 5: "8b", 6: "4s"}[tv[0]])
     wm, sc, wn = tv
     return "conv_igemm_kernel<{}, {}, {}, {}, {}>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
 
