@@ -24,6 +24,7 @@ class ConvDesc(Structure):
         ("ksize", c_int), ("stride", c_int), ("relu_upto", c_int), ("in_relu", c_int),
         ("tune_wm", c_int), ("tune_sc", c_int), ("tune_wn", c_int),
         ("w_wino", c_void_p),
+        ("in_scale", c_void_p), ("in_shift", c_void_p),
     ]
 
 
@@ -46,6 +47,7 @@ SIGNATURES = {
     "cmk_ese_gate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_ese_scale": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_groupnorm_relu_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "cmk_groupnorm_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "cmk_fcos_select": (c_int, [POINTER(FcosLevel), c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "cmk_fcos_select_ws_len": (c_int64, [POINTER(FcosLevel), c_int, c_int, c_int]),

@@ -44,6 +44,7 @@ __host__ __device__ constexpr int occ_of(int wm, int wn, int stride) { return (s
 
 struct ConvProblem {
     const float* x; float* y; const float* scale; const float* shift;
+    const float* in_scale; const float* in_shift;   // optional (N, Cin): x' = relu(x * in_scale + in_shift) while staging (fused GroupNorm+ReLU)
     int N, H, W, Ho, Wo;
     int tiles_h, tiles_w, tile_begin;
     long total_pix;  // N*Ho*Wo
@@ -143,10 +144,21 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
     }
     f32x4 a_stage[G::A_ITERS];
     f32x4 b_stage[G::B_ITERS];
+    // fused input affine (GroupNorm apply + ReLU of the producer): the channel quad of a thread is fixed (idx & 3 == tid & 3)
+    const bool has_aff = P.in_scale != nullptr;
+    int aff_n = n;                                   // 1x1 (flattened pixels): image index of this tile's first pixel; tiles never
+    if (TAPS != 9 && has_aff) aff_n = (int)(pix0 / ((long)Ho * Wo));   // straddle images when the affine is used (checked on the host)
+    const float* aff_s = has_aff ? P.in_scale + (long)aff_n * a.Cin + (tid & 3) * 4 : nullptr;
+    const float* aff_b = has_aff ? P.in_shift + (long)aff_n * a.Cin + (tid & 3) * 4 : nullptr;
+    f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
 
     auto load_A = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < G::A_ITERS; ++it) a_stage[it] = *reinterpret_cast<const f32x4*>(xin + a_goff[it] + chunk * 16);
+        if (has_aff) {
+            in_sc = *reinterpret_cast<const f32x4*>(aff_s + chunk * 16);
+            in_sh = *reinterpret_cast<const f32x4*>(aff_b + chunk * 16);
+        }
     };
     auto store_A = [&](int buf) {
         float* dst = sA + buf * (G::APIX * PST);
@@ -156,6 +168,10 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
             if ((it + 1) * 256 <= G::APIX * 4 || idx < G::APIX * 4) {
                 f32x4 v = a_stage[it];
                 const bool ok = (a_ok >> it) & 1u;
+                if (has_aff) {
+                    v.x = fmaxf(v.x * in_sc.x + in_sh.x, 0.f); v.y = fmaxf(v.y * in_sc.y + in_sh.y, 0.f);
+                    v.z = fmaxf(v.z * in_sc.z + in_sh.z, 0.f); v.w = fmaxf(v.w * in_sc.w + in_sh.w, 0.f);
+                }
                 if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 v.x = ok ? v.x : 0.f;
                 v.y = ok ? v.y : 0.f;
@@ -957,9 +973,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
         g_off[it] = off;
     }
     f32x4 h_stage[S_H_ITERS];
+    const bool has_aff = P.in_scale != nullptr;      // fused GroupNorm apply + ReLU of the producer
+    const float* aff_s = has_aff ? P.in_scale + (long)n * a.Cin + (tid & 3) * 4 : nullptr;
+    const float* aff_b = has_aff ? P.in_shift + (long)n * a.Cin + (tid & 3) * 4 : nullptr;
+    f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
     auto load_H = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < S_H_ITERS; ++it) h_stage[it] = *reinterpret_cast<const f32x4*>(xin + g_off[it] + chunk * 16);
+        if (has_aff) {
+            in_sc = *reinterpret_cast<const f32x4*>(aff_s + chunk * 16);
+            in_sh = *reinterpret_cast<const f32x4*>(aff_b + chunk * 16);
+        }
     };
     auto store_H = [&]() {
 #pragma unroll
@@ -968,6 +992,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
             if ((it + 1) * 256 <= S_HALO * 4 || idx < S_HALO * 4) {
                 f32x4 v = h_stage[it];
                 const bool k = (ok >> it) & 1u;
+                if (has_aff) {
+                    v.x = fmaxf(v.x * in_sc.x + in_sh.x, 0.f); v.y = fmaxf(v.y * in_sc.y + in_sh.y, 0.f);
+                    v.z = fmaxf(v.z * in_sc.z + in_sh.z, 0.f); v.w = fmaxf(v.w * in_sc.w + in_sh.w, 0.f);
+                }
                 v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
                 *reinterpret_cast<f32x4*>(sH + (idx >> 2) * PST + (idx & 3) * 4) = v;
             }
@@ -1262,11 +1290,14 @@ static int validate(const cmk_conv_desc* d) {
     if (((uintptr_t)d->x & 15) || ((uintptr_t)d->w & 15)) return fail(CMK_EINVAL, "conv: x/w must be 16-byte aligned%s", "");
     if (d->x_co + d->Cin > d->x_cs || d->y_co + d->Cout > d->y_cs) return fail(CMK_EINVAL, "conv: channel view out of range%s", "");
     if (d->res_mode < 0 || d->res_mode > 2 || (d->res_mode && !d->res)) return fail(CMK_EINVAL, "conv: bad residual%s", "");
+    if ((d->in_scale == nullptr) != (d->in_shift == nullptr)) return fail(CMK_EINVAL, "conv: in_scale and in_shift come together%s", "");
+    if (d->in_scale && d->ksize == 1 && ((long)d->H * d->W) % 256) return fail(CMK_EINVAL, "conv: input affine on a 1x1 conv needs H*W %% 256 == 0%s", "");
     return CMK_OK;
 }
 
 static void fill_problem(ConvProblem& p, const cmk_conv_desc* d) {
     p.x = d->x; p.y = d->y; p.scale = d->scale; p.shift = d->shift;
+    p.in_scale = d->in_scale; p.in_shift = d->in_shift;
     p.N = d->N; p.H = d->H; p.W = d->W;
     p.Ho = d->stride == 1 ? d->H : (d->H - 1) / 2 + 1;  // k3 p1 s2: floor((H+2-3)/2)+1
     p.Wo = d->stride == 1 ? d->W : (d->W - 1) / 2 + 1;
@@ -1290,7 +1321,7 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const int taps = d->ksize * d->ksize;
     hipStream_t st = (hipStream_t)stream;
     if (d->tune_wm >= 3 && d->tune_wm <= 6) {          // Winograd F(2x2,3x3) (3 = 4 waves, 4 = 8 waves, 5 = 8 waves with register-staged patches, 6 = 4 waves x 2 workgroups per CU): 3x3 stride 1, no residual / input ReLU
-        if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino)
+        if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino || (d->in_scale && d->tune_wm != 6))
             return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
         a.w = d->w_wino;
         if (d->tune_wm == 5 && (long)d->H * d->W * d->x_cs >= (1L << 31)) return fail(CMK_EINVAL, "conv: image too large for 32-bit patch offsets%s", "");
@@ -1340,7 +1371,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
         if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
-            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino)
+            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || (b->in_scale == nullptr) != (a->in_scale == nullptr))
             return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
     }
     return run(descs, n, stream);

@@ -236,6 +236,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(float* __restrict__ x, co
     }
 }
 
+// finalize: per (image, channel) scale/shift of GroupNorm for a consumer that applies it while staging its input
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ ws, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ out_scale,
+                                                         float* __restrict__ out_shift, int HW, int C, int groups, int chunks, float eps) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int n = blockIdx.x;
+    if (threadIdx.x < groups) {
+        double a = 0.0, b = 0.0;
+        const double* w = ws + ((long)n * groups + threadIdx.x) * chunks * 2;
+        for (int k = 0; k < chunks; ++k) { a += w[2 * k]; b += w[2 * k + 1]; }
+        double cnt = (double)HW * (C / groups);
+        double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[threadIdx.x] = (float)mean;
+        s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sc = s_rstd[c / cpg] * gamma[c];
+        out_scale[(long)n * C + c] = sc;
+        out_shift[(long)n * C + c] = beta[c] - s_mean[c / cpg] * sc;
+    }
+}
+
 static inline int stream_grid(long work_items) {
     long b = (work_items + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -312,4 +338,17 @@ extern "C" int cmk_groupnorm_relu_nhwc(float* x, const float* gamma, const float
     hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, ws, HW, C, groups, ws_chunks, eps,
                        bpi);
     return check_launch("gn_apply");
+}
+
+extern "C" int cmk_groupnorm_affine(const float* x, const float* gamma, const float* beta, double* ws, int ws_chunks, int N, int HW, int C,
+                                    int groups, float eps, float* out_scale, float* out_shift, void* stream) {
+    if (!x || !gamma || !beta || !ws || !out_scale || !out_shift) return fail(CMK_EINVAL, "groupnorm_affine: null pointer%s", "");
+    if ((C & 3) || C > 1024 || groups < 1 || groups > 64 || C % groups || ((C / groups) & 3) || 256 % (C >> 2) || ws_chunks < 1)
+        return fail(CMK_EINVAL, "groupnorm_affine: unsupported C/groups%s", "");
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(ws_chunks, N), dim3(256), 0, (hipStream_t)stream, x, ws, HW, C, groups, ws_chunks);
+    int rc = check_launch("gn_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ws, gamma, beta, out_scale, out_shift, HW, C, groups,
+                       ws_chunks, eps);
+    return check_launch("gn_finalize");
 }

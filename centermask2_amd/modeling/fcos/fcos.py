@@ -101,16 +101,18 @@ class FCOSHead(HipModule):
         return P
 
     @staticmethod
-    def _run_tower(xs: List[View], tower) -> List[View]:
-        """One launch per tower conv over ALL levels (the weights are shared, fcos.py:227-231), then GN+ReLU per level."""
+    def _run_tower(xs: List[View], tower, aff=None):
+        """One launch per tower conv over ALL levels (the weights are shared, fcos.py:227-231).  GroupNorm+ReLU is not a pass
+        of its own: its statistics become a per-(image, channel) affine that the NEXT conv applies while staging its input.
+        Returns (raw conv outputs, pending affine or None)."""
         for pc, gamma, beta, eps, groups in tower:
             if gamma is None:
-                xs = ops.conv_out_multi(xs, [pc] * len(xs), relu=True)
+                xs = ops.conv_out_multi(xs, [pc] * len(xs), relu=True, in_affine=aff)
+                aff = None
             else:
-                xs = ops.conv_out_multi(xs, [pc] * len(xs))
-                for x in xs:
-                    ops.groupnorm_relu_(x.t, gamma, beta, groups, eps)
-        return xs
+                xs = ops.conv_out_multi(xs, [pc] * len(xs), in_affine=aff)
+                aff = [ops.groupnorm_affine(x.t, gamma, beta, groups, eps) for x in xs]
+        return xs, aff
 
     def forward_views(self, feats: List[View]):
         """-> (logits[l] (N,H,W,C) NHWC, regctr[l] (N,H,W,5) = [relu(scale_l*bbox_pred) x4, ctrness logit])."""
@@ -118,11 +120,11 @@ class FCOSHead(HipModule):
         nl = len(feats)
         out_l, out_r = [], []
         for g0 in range(0, nl, 5):                      # the multi-problem launch takes up to 5 levels
-            f = self._run_tower(list(feats[g0:g0 + 5]), P["share"])
-            cls_t = self._run_tower(f, P["cls"])
-            box_t = self._run_tower(f, P["bbox"])
-            out_l += [v.t for v in ops.conv_out_multi(cls_t, [P["cls_logits"]] * len(cls_t))]
-            out_r += [v.t for v in ops.conv_out_multi(box_t, P["regctr"][g0:g0 + 5], relu_upto=4)]       # fcos.py:233-238
+            f, fa = self._run_tower(list(feats[g0:g0 + 5]), P["share"])
+            cls_t, ca = self._run_tower(f, P["cls"], fa)
+            box_t, ba = self._run_tower(f, P["bbox"], fa)
+            out_l += [v.t for v in ops.conv_out_multi(cls_t, [P["cls_logits"]] * len(cls_t), in_affine=ca)]
+            out_r += [v.t for v in ops.conv_out_multi(box_t, P["regctr"][g0:g0 + 5], relu_upto=4, in_affine=ba)]       # fcos.py:233-238
         return out_l, out_r
 
     def forward(self, x: List[torch.Tensor]):

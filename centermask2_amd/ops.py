@@ -123,7 +123,7 @@ def fold_frozen_bn(weight, bias, running_mean, running_var, eps=1e-5):
     return scale.float(), shift.float()
 
 
-def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, res, res_upsample, in_relu) -> None:
+def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, res, res_upsample, in_relu, in_affine=None) -> None:
     _need_gpu(x.t, "conv2d")
     n, h, w = x.nhw
     d.x, d.x_cs, d.x_co = x.t.data_ptr(), x.cs, x.co
@@ -146,6 +146,10 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
     d.ksize, d.stride = pc.k, pc.stride
     d.relu_upto = (pc.cout if relu else 0) if relu_upto is None else relu_upto
     d.in_relu = int(in_relu)
+    if in_affine is not None:
+        d.in_scale, d.in_shift = in_affine[0].data_ptr(), in_affine[1].data_ptr()
+    else:
+        d.in_scale = d.in_shift = None
 
 
 # ---- tile-variant autotuning (host side; the library itself stays stateless) -----------------------------------
@@ -236,7 +240,9 @@ def _apply_tuning(descs, n, key) -> None:
 
 def _problem_key(descs, n):
     d = descs[0]
-    return (d.ksize, d.stride, d.Cin, d.Cout, d.x_cs, d.y_cs, d.res_mode, tuple((descs[i].N, descs[i].H, descs[i].W) for i in range(n)))
+    # res slot: 0/1/2 = residual mode, +4 when the fused input affine is on (restricts the variants that may be chosen)
+    return (d.ksize, d.stride, d.Cin, d.Cout, d.x_cs, d.y_cs, d.res_mode + (4 if d.in_scale else 0),
+            tuple((descs[i].N, descs[i].H, descs[i].W) for i in range(n)))
 
 
 def conv2d(x: View, pc: PackedConv, y: View, relu: bool = False, relu_upto: Optional[int] = None,
@@ -249,19 +255,20 @@ def conv2d(x: View, pc: PackedConv, y: View, relu: bool = False, relu_upto: Opti
 
 
 def conv2d_multi(xs: Sequence[View], pcs: Sequence[PackedConv], ys: Sequence[View], relu: bool = False,
-                 relu_upto: Optional[int] = None) -> None:
-    """One launch over several inputs that share the packed weights (pcs[i].w is the same tensor; scale/shift may differ)."""
+                 relu_upto: Optional[int] = None, in_affine=None) -> None:
+    """One launch over several inputs that share the packed weights (pcs[i].w is the same tensor; scale/shift may differ).
+    in_affine[i] = (scale, shift) of shape (N, Cin): the producer's GroupNorm+ReLU applied while staging input i."""
     lib = _lib.load()
     n = len(xs)
     descs = (ConvDesc * n)()
     for i in range(n):
         assert pcs[i].w.data_ptr() == pcs[0].w.data_ptr()
-        _fill_desc(descs[i], xs[i], pcs[i], ys[i], relu, relu_upto, None, False, False)
+        _fill_desc(descs[i], xs[i], pcs[i], ys[i], relu, relu_upto, None, False, False, in_affine[i] if in_affine is not None else None)
     _apply_tuning(descs, n, _problem_key(descs, n))
     check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi")
 
 
-def conv_out_multi(xs: Sequence[View], pcs: Sequence[PackedConv], **kw) -> List[View]:
+def conv_out_multi(xs: Sequence[View], pcs: Sequence[PackedConv], **kw) -> List[View]:  # kw: relu, relu_upto, in_affine
     ys = [View(torch.empty((x.t.shape[0], x.t.shape[1], x.t.shape[2], pcs[0].cout), dtype=torch.float32, device=x.t.device)) for x in xs]
     conv2d_multi(xs, pcs, ys, **kw)
     return ys
@@ -330,6 +337,22 @@ def ese(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor, y: View, identity: Opti
     idp, idcs, idco = (identity.t.data_ptr(), identity.cs, identity.co) if identity is not None else (None, 0, 0)
     check(lib.cmk_ese_scale(x.t.data_ptr(), x.cs, x.co, gate.data_ptr(), idp, idcs, idco, y.t.data_ptr(), y.cs, y.co,
                             n, hw, c, _stream()), "cmk_ese_scale")
+
+
+def groupnorm_affine(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-5):
+    """GroupNorm statistics of a dense NHWC tensor as per-(image, channel) (scale, shift); the consumer conv applies
+    relu(x*scale + shift) while staging (cmk_conv_desc.in_scale/in_shift), so the normalised tensor is never written."""
+    lib = _lib.load()
+    _need_gpu(x, "groupnorm_affine")
+    n, h, w, c = x.shape
+    hw = h * w
+    chunks = max(1, min(128, hw // 128))
+    ws = torch.empty((n, groups, chunks, 2), dtype=torch.float64, device=x.device)
+    sc = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    sh = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(lib.cmk_groupnorm_affine(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), chunks, n, hw, c, groups, eps,
+                                   sc.data_ptr(), sh.data_ptr(), _stream()), "cmk_groupnorm_affine")
+    return sc, sh
 
 
 def groupnorm_relu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-5) -> None:
@@ -503,7 +526,8 @@ def conv2d_multi(xs, pcs, ys, **kw):  # noqa: F811
     e1.record()
     descs = (ConvDesc * len(xs))()
     for i in range(len(xs)):
-        _fill_desc(descs[i], xs[i], pcs[i], ys[i], kw.get("relu", False), kw.get("relu_upto"), None, False, False)
+        _fill_desc(descs[i], xs[i], pcs[i], ys[i], kw.get("relu", False), kw.get("relu_upto"), None, False, False,
+                   kw["in_affine"][i] if kw.get("in_affine") is not None else None)
     PROFILE.append((_kernel_name(taps, 1, _TUNED.get(_problem_key(descs, len(xs)))), flops, nbytes, e0, e1, None))
 
 

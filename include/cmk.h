@@ -55,6 +55,10 @@ typedef struct {
      * step g streams the frequencies {2g, 2g+1, 8+2g, 9+2g} of the row-major 4x4 frequency grid; within a 64-byte row
      * (one co, 16 ci) the 16-byte chunk at position p holds logical chunk p ^ ((co >> 2) & 3) (the LDS swizzle). */
     const float* w_wino;
+    /* optional fused GroupNorm+ReLU of the PRODUCER (fcos.py:182-186): per (image, input channel) x' = relu(x*in_scale + in_shift)
+     * is applied while the input tile is staged, so the normalised tensor is never written; arrays of N*Cin floats from
+     * cmk_groupnorm_affine.  Supported by the direct kernels and Winograd form 6. */
+    const float* in_scale; const float* in_shift;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
 /* Same conv applied to up to 5 inputs of different H x W in ONE launch (the FCOS towers/predictors share their weights
@@ -85,6 +89,11 @@ int cmk_ese_scale(const float* x, int x_cs, int x_co, const float* gate, const f
  * ws: N * groups * gn_chunks * 2 doubles.                                                                    */
 int cmk_groupnorm_relu_nhwc(float* x, const float* gamma, const float* beta, double* ws, int ws_chunks,
                             int N, int HW, int C, int groups, float eps, void* stream);
+
+/* Statistics only: out_scale/out_shift (N*C each) such that GroupNorm(x)[n,:,c] = x*out_scale[n,c] + out_shift[n,c];
+ * the consumer conv applies them (cmk_conv_desc.in_scale/in_shift).  ws as above. */
+int cmk_groupnorm_affine(const float* x, const float* gamma, const float* beta, double* ws, int ws_chunks,
+                         int N, int HW, int C, int groups, float eps, float* out_scale, float* out_shift, void* stream);
 
 /* ---- FCOS candidate selection + box decode (fcos_outputs.py:396-466) ------------------------------------------ */
 typedef struct {

@@ -195,3 +195,29 @@ def test_conv_winograd_variant(dev, case, waves):
     _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "wino")
     torch.cuda.synchronize()
     _close(y.nchw(), ref)
+
+
+@pytest.mark.parametrize("variant", [(0, 0, 0), (6, 16, 2), (1, 16, 1)])
+def test_conv_fused_groupnorm_relu_input(dev, variant):
+    """conv(relu(GroupNorm(x))) with the GN apply fused into the conv's input staging (direct kernels and Winograd form 6)."""
+    import ctypes
+    from centermask2_amd import _lib
+    n, h, w, c, cout = 2, 25, 40, 256, 80
+    x = _rand((n, c, h, w), 91, 2.0) + 0.7
+    gamma = torch.rand(c, generator=torch.Generator().manual_seed(92)) + 0.5
+    beta = _rand((c,), 93, 0.2)
+    wt = _rand((cout, c, 3, 3), 94, 0.03)
+    bias = _rand((cout,), 95, 0.1)
+    ref = F.conv2d(F.relu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), wt, bias, padding=1)
+    xv = ops.as_view(x.to(dev))
+    aff = ops.groupnorm_affine(xv.t, gamma.to(dev), beta.to(dev))
+    pc = ops.PackedConv(wt, None, bias, dev)
+    y = View(torch.empty((n, h, w, cout), device=dev))
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], xv, pc, y, False, None, None, False, False, aff)
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = variant
+    _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "conv+gn")
+    torch.cuda.synchronize()
+    _close(y.nchw(), ref)
+    d[0].tune_wm = 4          # Winograd forms without the fused affine must refuse rather than ignore it
+    assert _lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
