@@ -1332,6 +1332,12 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         v = Variant{d->tune_wm, d->tune_sc, d->tune_wn};
         if (!variant_ok(taps, d->stride, cout32, v.wm, v.sc, v.wn)) return fail(CMK_EINVAL, "conv: variant not available for this shape%s", "");
     } else {
+        // untuned default: the 2-WG/CU Winograd form wins on every 3x3 stride-1 shape measured (tools/bench_wino.py), so take it
+        // whenever the caller packed the transformed weights; otherwise the direct-kernel cost model decides
+        if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && d->w_wino && d->Cin >= 32) {
+            a.w = d->w_wino;
+            return launch_wino(a, 3, st);
+        }
         v = choose_variant(a, taps, d->stride, cout32);
     }
     if (d->ksize == 1) return dispatch_wn<1, 1>(a, cout32, v, st);
