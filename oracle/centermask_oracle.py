@@ -488,3 +488,27 @@ def detector_postprocess(res: dict, h: int, w: int, mask_threshold=0.5) -> dict:
     out["boxes"] = boxes[keep]
     out["pred_masks"] = paste_masks(out["pred_masks"][:, 0], out["boxes"], h, w, mask_threshold)
     return out
+
+
+def roi_align_boundary_margin(boxes: torch.Tensor, levels: torch.Tensor, feat_hw: List[Tuple[int, int]], scales=(1 / 8, 1 / 16, 1 / 32),
+                              out_size: int = 14) -> torch.Tensor:
+    """Conditioning of ROIAlign per ROI (test helper): the smallest distance, in feature pixels, of any bilinear sample coordinate to
+    the validity boundaries of torchvision's kernel (coordinate == -1 or == size: on one side the sample contributes the clamped
+    edge pixel, on the other side 0).  An ROI whose margin is below the box tolerance is discontinuous in the box coordinates for the
+    reference op itself; parity tests skip its mask values."""
+    out = torch.full((boxes.shape[0],), float("inf"))
+    for i in range(boxes.shape[0]):
+        lv = int(levels[i])
+        h, w = feat_hw[lv]
+        s = scales[lv]
+        for lo, hi, size in ((float(boxes[i, 0]), float(boxes[i, 2]), w), (float(boxes[i, 1]), float(boxes[i, 3]), h)):
+            start, length = lo * s - 0.5, (hi - lo) * s
+            grid = max(int(math.ceil(length / out_size)), 0)
+            if grid == 0:
+                continue
+            p = torch.arange(out_size, dtype=torch.float64)[:, None]
+            k = torch.arange(grid, dtype=torch.float64)[None, :]
+            c = start + p * (length / out_size) + (k + 0.5) * (length / out_size) / grid
+            m = torch.minimum((c + 1.0).abs(), (c - size).abs()).min()
+            out[i] = min(float(out[i]), float(m))
+    return out

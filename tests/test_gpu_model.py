@@ -135,7 +135,15 @@ def test_v99_backbone_and_full_model_run(dev):
     want = O.centermask_inference(sd, x, [(128, 192)], "V-99-eSE")[0]
     assert len(res[0]) == want["scores"].shape[0]
     assert torch.equal(res[0].pred_classes.cpu(), want["classes"]) and torch.equal(res[0].locations.cpu(), want["locations"])
-    close(res[0].pred_masks, want["pred_masks"], 1e-3)
+    close(res[0].pred_boxes.tensor, want["boxes"], 1e-4, "boxes")
+    # ROIAlign is discontinuous where a sample coordinate sits on the validity boundary (-1 / size) of torchvision's kernel: with
+    # this tiny image the boxes reach far outside it, and a 0.02 px box difference can flip one sample of one ROI between "edge
+    # pixel" and 0 (in the reference op too).  Such ill-conditioned ROIs are identified with the oracle and left out.
+    levels = O.assign_boxes_to_levels_by_ratio(want["boxes"], torch.full((len(res[0]),), 128.0 * 192.0))
+    margin = O.roi_align_boundary_margin(want["boxes"], levels, [(16, 24), (8, 12), (4, 6)])
+    well = margin > 2e-3            # box tolerance 0.03 px at stride 32 is 1e-3 feature pixels
+    assert int(well.sum()) >= len(res[0]) - 5, margin
+    close(res[0].pred_masks[well.to(dev)], want["pred_masks"][well], 1e-3, "masks of well-conditioned ROIs")
 
 
 def test_inference_with_pre_and_postprocess(dev, model):
