@@ -173,3 +173,22 @@ def test_all_gather_world_size_2_gloo(tmp_path):
              for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_average_precision_known_answers():
+    from centermask2_amd.evaluation import average_precision, box_iou
+    gt = [dict(boxes=torch.tensor([[0., 0., 10., 10.], [20., 20., 40., 40.]]), classes=torch.tensor([1, 2]))]
+    perfect = [dict(boxes=gt[0]["boxes"].clone(), classes=gt[0]["classes"].clone(), scores=torch.tensor([0.9, 0.8]))]
+    assert average_precision(perfect, gt, "box") == pytest.approx(1.0)
+    # one box shifted so that IoU = 0.6: counted at thresholds .50-.60 only (3 of 10) for class 1; class 2 perfect
+    shifted = [dict(boxes=torch.tensor([[2.5, 0., 12.5, 10.], [20., 20., 40., 40.]]), classes=torch.tensor([1, 2]), scores=torch.tensor([0.9, 0.8]))]
+    assert float(box_iou(shifted[0]["boxes"][:1], gt[0]["boxes"][:1])) == pytest.approx(0.6)
+    assert average_precision(shifted, gt, "box") == pytest.approx((0.3 + 1.0) / 2, abs=1e-6)
+    # a higher-scored false positive in front of the true positive halves the precision of class 1
+    fp = [dict(boxes=torch.tensor([[50., 50., 60., 60.], [0., 0., 10., 10.], [20., 20., 40., 40.]]), classes=torch.tensor([1, 1, 2]),
+               scores=torch.tensor([0.95, 0.9, 0.8]))]
+    assert average_precision(fp, gt, "box") == pytest.approx((0.5 + 1.0) / 2, abs=1e-6)
+    m = torch.zeros((2, 8, 8), dtype=torch.bool); m[0, :4] = True; m[1, 4:] = True
+    gm = [dict(boxes=gt[0]["boxes"], classes=torch.tensor([1, 1]), masks=m)]
+    pm = [dict(boxes=gt[0]["boxes"], classes=torch.tensor([1, 1]), masks=m.clone(), scores=torch.tensor([0.1, 0.9]), mask_scores=torch.tensor([0.9, 0.1]))]
+    assert average_precision(pm, gm, "mask") == pytest.approx(1.0)
