@@ -26,7 +26,8 @@ def mask_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     af, bf = a.flatten(1).float(), b.flatten(1).float()
     inter = af @ bf.t()
     union = af.sum(1)[:, None] + bf.sum(1)[None, :] - inter
-    return inter / union.clamp(min=1.0)
+    iou = inter / union.clamp(min=1.0)
+    return torch.where(union == 0, torch.ones_like(iou), iou)      # two empty masks (box outside the image) coincide
 
 
 def average_precision(preds: List[Dict[str, torch.Tensor]], gts: List[Dict[str, torch.Tensor]], kind: str = "box") -> float:
