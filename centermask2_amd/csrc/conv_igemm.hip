@@ -1011,27 +1011,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     const int t_half = tid >> 7, t_tile = (tid >> 2) & 31, t_q = tid & 3;
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
     const int v_chunk = (t_q ^ ((t_tile >> 2) & 3)) * 4;
-    auto transform = [&]() {
+    // Input transform of one frequency row pair: part 0 -> rows {0, 2} (frequencies 0-3 / 8-11, used by steps 0-1),
+    // part 1 -> rows {1, 3} (frequencies 4-7 / 12-15, used by steps 2-3).  Thread half h2 owns rows {2*h2, 2*h2+1}.
+    auto transform_part = [&](int ii) {
         const float* src = sH + ((2 * t_ty + t_half) * 18 + 2 * t_tx) * PST + t_q * 4;
-        f32x4 x0[4], x1[4];
+        f32x4 x[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 da = *reinterpret_cast<const f32x4*>(src + (0 * 18 + j) * PST);
             f32x4 db = *reinterpret_cast<const f32x4*>(src + (1 * 18 + j) * PST);
             f32x4 dc = *reinterpret_cast<const f32x4*>(src + (2 * 18 + j) * PST);
-            if (t_half == 0) { x0[j] = da - dc; x1[j] = db + dc; }
-            else             { x0[j] = db - da; x1[j] = da - dc; }
+            if (t_half == 0) x[j] = ii == 0 ? (da - dc) : (db + dc);     // rows 0,1 of B^T d from d0,d1,d2
+            else             x[j] = ii == 0 ? (db - da) : (da - dc);     // rows 2,3 of B^T d from d1,d2,d3
         }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const f32x4* x = ii == 0 ? x0 : x1;
-            f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
-            float* dst = sV + (((2 * t_half + ii) * 4) * 32 + t_tile) * 16 + v_chunk;
-            *reinterpret_cast<f32x4*>(dst + 0 * 32 * 16) = v0;
-            *reinterpret_cast<f32x4*>(dst + 1 * 32 * 16) = v1;
-            *reinterpret_cast<f32x4*>(dst + 2 * 32 * 16) = v2;
-            *reinterpret_cast<f32x4*>(dst + 3 * 32 * 16) = v3;
-        }
+        f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
+        float* dst = sV + (((2 * t_half + ii) * 4) * 32 + t_tile) * 16 + v_chunk;
+        *reinterpret_cast<f32x4*>(dst + 0 * 32 * 16) = v0;
+        *reinterpret_cast<f32x4*>(dst + 1 * 32 * 16) = v1;
+        *reinterpret_cast<f32x4*>(dst + 2 * 32 * 16) = v2;
+        *reinterpret_cast<f32x4*>(dst + 3 * 32 * 16) = v3;
     };
 
     f32x16 acc[8];
@@ -1045,11 +1043,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     const float* Abase = sV + ((fh * 8) * 32 + li) * 16;
     const int b_row = ((fh * 2) * 64 + ng * 32 + li) * 16;
 
+    // Schedule (4 barriers per chunk, no staging phase of its own): everything that is not an MFMA is issued right AFTER a
+    // step's MFMAs, so it executes in their shadow.
+    //   step 0: + second half of THIS chunk's input transform (frequencies 4-7/12-15, first needed in step 2)
+    //   step 1: + halo of the NEXT chunk, registers -> LDS (the loads were issued in step 0)
+    //   step 2: + first half of the NEXT chunk's transform (frequencies 0-3/8-11, last read in step 1)
+    // Frequency rows are renumbered so that steps 0-1 use only "part 0" rows: step g streams {2g,2g+1} of each half, i.e.
+    // local accumulators g*2+fl -> frequency index fh*8 + (g*2+fl); part 0 = local 0-3, part 1 = local 4-7.
     load_H(0);
     glds_U(0, 0);
     store_H();
     __syncthreads();
-    transform();
+    transform_part(0);
 
     const int total_steps = nchunks * 4;
     for (int c = 0; c < nchunks; ++c) {
@@ -1057,7 +1062,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int step = c * 4 + g;
-            __syncthreads();          // V (g == 0) and U[g & 1] landed and visible; everyone is done with the previous step
+            __syncthreads();          // U[g & 1] landed; V rows and halo written in earlier steps are visible; previous step is done
             if (step + 1 < total_steps) glds_U(step + 1, (g + 1) & 1);
             if (g == 0 && has_next_chunk) load_H(c + 1);
             const float* B = sU + (g & 1) * S_SU + b_row;
@@ -1073,12 +1078,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[al], 0, 0, 0);
             }
-        }
-        if (has_next_chunk) {
-            __syncthreads();          // every wave is done reading V (and the halo was consumed by the last transform)
-            store_H();
-            __syncthreads();
-            transform();
+            if (g == 0) transform_part(1);                       // this chunk, rows used from step 2 on
+            if (g == 1 && has_next_chunk) store_H();             // everyone finished reading the old halo in step 0
+            if (g == 2 && has_next_chunk) transform_part(0);     // next chunk, rows last read in step 1
         }
     }
 
