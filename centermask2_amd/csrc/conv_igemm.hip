@@ -742,6 +742,14 @@ constexpr int W2_LDS_BYTES = (W_SV + 2 * W2_SU) * 4;         // 80 KiB + 64 KiB
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// Barrier for kernels with global_load_lds in flight.  hipcc does not reliably put the `s_waitcnt vmcnt(0)` in front of a
+// __syncthreads() that guards LDS-DMA data (it was dropped on a rotated loop back-edge here: correct on warm caches, wrong on
+// the first, cold launch), so the drain is written out: every wave retires its own DMA pieces, then the barrier publishes them.
+__device__ __forceinline__ void lds_dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(512, 2) void conv_wino8b_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sV = smem;
@@ -845,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino8b_kernel(const ConvArgs a) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const int step = c * 2 + st;
-            __syncthreads();          // V (st == 0) and U[st] landed and visible; everyone is done with the previous step
+            lds_dma_barrier();          // V (st == 0) and U[st] landed and visible; everyone is done with the previous step
             if (step + 1 < total_steps) glds_U(step + 1, st ^ 1);          // in flight during this step's MFMAs
             if (st == 0 && has_next_chunk) load_P(c + 1);
             const float* B = sU + st * W2_SU + b_row;
@@ -865,13 +873,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino8b_kernel(const ConvArgs a) {
                 }
         }
         if (has_next_chunk) {
-            __syncthreads();          // every wave is done reading V of this chunk
+            lds_dma_barrier();          // every wave is done reading V of this chunk
             transform();
         }
     }
 
     // ---- output transform: own half in registers, partner's half through LDS (as in conv_wino8_kernel) ------------------
-    __syncthreads();
+    lds_dma_barrier();
     float* ex = sV;
     float keep[16][2];
 #pragma unroll
@@ -894,7 +902,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino8b_kernel(const ConvArgs a) {
         ex[((wave * 16 + r) * 2 + 0) * 64 + lane] = send0;
         ex[((wave * 16 + r) * 2 + 1) * 64 + lane] = send1;
     }
-    __syncthreads();
+    lds_dma_barrier();
     const int partner = wave ^ 4;
     const int co = co0 + ng * 32 + li;
     const bool cvalid = co < a.Cout;
@@ -1053,7 +1061,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     load_H(0);
     glds_U(0, 0);
     store_H();
-    __syncthreads();
+    lds_dma_barrier();
     transform_part(0);
 
     const int total_steps = nchunks * 4;
@@ -1062,7 +1070,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int step = c * 4 + g;
-            __syncthreads();          // U[g & 1] landed; V rows and halo written in earlier steps are visible; previous step is done
+            lds_dma_barrier();          // U[g & 1] landed; V rows and halo written in earlier steps are visible; previous step is done
             if (step + 1 < total_steps) glds_U(step + 1, (g + 1) & 1);
             if (g == 0 && has_next_chunk) load_H(c + 1);
             const float* B = sU + (g & 1) * S_SU + b_row;
@@ -1084,7 +1092,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
         }
     }
 
-    __syncthreads();
+    lds_dma_barrier();
     float* ex = sV;                        // [wave 4][r 16][2][64 lanes] = 32 KiB
     float keep[16][2];
 #pragma unroll
@@ -1107,7 +1115,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
         ex[((wave * 16 + r) * 2 + 0) * 64 + lane] = send0;
         ex[((wave * 16 + r) * 2 + 1) * 64 + lane] = send1;
     }
-    __syncthreads();
+    lds_dma_barrier();
     const int partner = wave ^ 2;
     const int co = co0 + ng * 32 + li;
     const bool cvalid = co < a.Cout;
