@@ -48,6 +48,8 @@ SIGNATURES = {
     "cmk_ese_scale": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_groupnorm_relu_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "cmk_groupnorm_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "cmk_groupnorm_affine_multi": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                           POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     "cmk_fcos_select": (c_int, [POINTER(FcosLevel), c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "cmk_fcos_select_ws_len": (c_int64, [POINTER(FcosLevel), c_int, c_int, c_int]),

@@ -14,7 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        float* __restrict__ y, int N, int H, int W, int Ho, int Wo, int Cout) {
-    extern __shared__ float sw[];  // [27][Cout] + scale[Cout] + shift[Cout]
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // [27][Cout] + scale[Cout] + shift[Cout]
     for (int i = threadIdx.x; i < 27 * Cout; i += 256) sw[i] = w[i];
     for (int i = threadIdx.x; i < Cout; i += 256) { sw[27 * Cout + i] = scale[i]; sw[28 * Cout + i] = shift[i]; }
     __syncthreads();
@@ -39,9 +39,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             for (int kw = 0; kw < 3; ++kw) {
                 int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
                 float v = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xn[((long)ci * H + ih) * W + iw] : 0.f;
-                const float* wr = sw + ((kh * 3 + kw) * 3 + ci) * Cout + g * 16;  // tap-major [kh][kw][ci][co]
+                const f32x4* wr = reinterpret_cast<const f32x4*>(sw + ((kh * 3 + kw) * 3 + ci) * Cout + g * 16);  // tap-major [kh][kw][ci][co]
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+                for (int j4 = 0; j4 < 4; ++j4) {      // 4 x ds_read_b128 per tap instead of 16 x ds_read_b32
+                    const f32x4 w4 = wr[j4];
+                    acc[j4 * 4 + 0] = fmaf(v, w4.x, acc[j4 * 4 + 0]);
+                    acc[j4 * 4 + 1] = fmaf(v, w4.y, acc[j4 * 4 + 1]);
+                    acc[j4 * 4 + 2] = fmaf(v, w4.z, acc[j4 * 4 + 2]);
+                    acc[j4 * 4 + 3] = fmaf(v, w4.w, acc[j4 * 4 + 3]);
+                }
             }
     float* yo = y + pix * Cout + g * 16;
 #pragma unroll
@@ -262,6 +268,75 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     }
 }
 
+// All FPN levels of one tower conv in one launch each (the per-level kernels are launch-latency sized).
+constexpr int GN_MAXL = 5;
+struct GnLevels {
+    const float* x[GN_MAXL];
+    float* out_scale[GN_MAXL];
+    float* out_shift[GN_MAXL];
+    int HW[GN_MAXL];
+    int nlev;
+};
+
+__global__ __launch_bounds__(256) void gn_stats_multi_kernel(const GnLevels L, double* __restrict__ ws, int N, int C, int groups, int chunks) {
+    __shared__ double rs[256], rss[256];
+    const int chunk = blockIdx.x, n = blockIdx.y, l = blockIdx.z;
+    const int HW = L.HW[l];
+    const int G = C >> 2;
+    const int ppl = 256 / G;
+    const int per = cdiv(HW, chunks);
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    const float* xn = L.x[l] + (long)n * HW * C;
+    double s = 0.0, ss = 0.0;
+    const int g = threadIdx.x % G, pl = threadIdx.x / G;
+    if (pl < ppl) {
+        for (int p = p0 + pl; p < p1; p += ppl) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xn + (long)p * C + g * 4);
+            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+    }
+    rs[threadIdx.x] = s;
+    rss[threadIdx.x] = ss;
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        const int f4pg = (C / groups) >> 2;
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < ppl; ++k)
+            for (int q = 0; q < f4pg; ++q) {
+                a += rs[k * G + threadIdx.x * f4pg + q];
+                b += rss[k * G + threadIdx.x * f4pg + q];
+            }
+        double* o = ws + ((((long)l * N + n) * groups + threadIdx.x) * chunks + chunk) * 2;
+        o[0] = a;
+        o[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_multi_kernel(const GnLevels L, const double* __restrict__ ws, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int N, int C, int groups, int chunks, float eps) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int n = blockIdx.x, l = blockIdx.y;
+    if (threadIdx.x < groups) {
+        double a = 0.0, b = 0.0;
+        const double* w = ws + (((long)l * N + n) * groups + threadIdx.x) * chunks * 2;
+        for (int k = 0; k < chunks; ++k) { a += w[2 * k]; b += w[2 * k + 1]; }
+        double cnt = (double)L.HW[l] * (C / groups);
+        double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[threadIdx.x] = (float)mean;
+        s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sc = s_rstd[c / cpg] * gamma[c];
+        L.out_scale[l][(long)n * C + c] = sc;
+        L.out_shift[l][(long)n * C + c] = beta[c] - s_mean[c / cpg] * sc;
+    }
+}
+
 static inline int stream_grid(long work_items) {
     long b = (work_items + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -351,4 +426,26 @@ extern "C" int cmk_groupnorm_affine(const float* x, const float* gamma, const fl
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ws, gamma, beta, out_scale, out_shift, HW, C, groups,
                        ws_chunks, eps);
     return check_launch("gn_finalize");
+}
+
+extern "C" int cmk_groupnorm_affine_multi(const float* const* xs, const int* HWs, int nlev, const float* gamma, const float* beta, double* ws,
+                                          int ws_chunks, int N, int C, int groups, float eps, float* const* out_scale, float* const* out_shift,
+                                          void* stream) {
+    if (!xs || !HWs || !gamma || !beta || !ws || !out_scale || !out_shift) return fail(CMK_EINVAL, "groupnorm_affine_multi: null pointer%s", "");
+    if (nlev < 1 || nlev > GN_MAXL) return fail(CMK_EINVAL, "groupnorm_affine_multi: 1..5 levels%s", "");
+    if ((C & 3) || C > 1024 || groups < 1 || groups > 64 || C % groups || ((C / groups) & 3) || 256 % (C >> 2) || ws_chunks < 1)
+        return fail(CMK_EINVAL, "groupnorm_affine_multi: unsupported C/groups%s", "");
+    GnLevels L;
+    L.nlev = nlev;
+    for (int l = 0; l < GN_MAXL; ++l) {
+        bool ok = l < nlev;
+        if (ok && (!xs[l] || !out_scale[l] || !out_shift[l] || HWs[l] < 1)) return fail(CMK_EINVAL, "groupnorm_affine_multi: bad level%s", "");
+        L.x[l] = ok ? xs[l] : nullptr; L.out_scale[l] = ok ? out_scale[l] : nullptr; L.out_shift[l] = ok ? out_shift[l] : nullptr;
+        L.HW[l] = ok ? HWs[l] : 1;
+    }
+    hipLaunchKernelGGL(gn_stats_multi_kernel, dim3(ws_chunks, N, nlev), dim3(256), 0, (hipStream_t)stream, L, ws, N, C, groups, ws_chunks);
+    int rc = check_launch("gn_stats_multi");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_finalize_multi_kernel, dim3(N, nlev), dim3(256), 0, (hipStream_t)stream, L, ws, gamma, beta, N, C, groups, ws_chunks, eps);
+    return check_launch("gn_finalize_multi");
 }

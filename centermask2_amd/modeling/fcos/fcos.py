@@ -111,7 +111,7 @@ class FCOSHead(HipModule):
                 aff = None
             else:
                 xs = ops.conv_out_multi(xs, [pc] * len(xs), in_affine=aff)
-                aff = [ops.groupnorm_affine(x.t, gamma, beta, groups, eps) for x in xs]
+                aff = ops.groupnorm_affine_multi([x.t for x in xs], gamma, beta, groups, eps)
         return xs, aff
 
     def forward_views(self, feats: List[View]):

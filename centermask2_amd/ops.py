@@ -355,6 +355,27 @@ def groupnorm_affine(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, g
     return sc, sh
 
 
+def groupnorm_affine_multi(xs: Sequence[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-5):
+    """groupnorm_affine for several dense NHWC tensors with the same (N, C) — the FPN levels — in two launches."""
+    lib = _lib.load()
+    nl = len(xs)
+    n, c = xs[0].shape[0], xs[0].shape[3]
+    dev = xs[0].device
+    chunks = 64
+    ws = torch.empty((nl, n, groups, chunks, 2), dtype=torch.float64, device=dev)
+    out = [(torch.empty((n, c), dtype=torch.float32, device=dev), torch.empty((n, c), dtype=torch.float32, device=dev)) for _ in xs]
+    px, ps, pb = (ctypes.c_void_p * nl)(), (ctypes.c_void_p * nl)(), (ctypes.c_void_p * nl)()
+    hws = (ctypes.c_int * nl)()
+    for i, x in enumerate(xs):
+        _need_gpu(x, "groupnorm_affine_multi")
+        assert x.is_contiguous() and x.shape[0] == n and x.shape[3] == c
+        px[i], ps[i], pb[i] = x.data_ptr(), out[i][0].data_ptr(), out[i][1].data_ptr()
+        hws[i] = x.shape[1] * x.shape[2]
+    check(lib.cmk_groupnorm_affine_multi(px, hws, nl, gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), chunks, n, c, groups, eps, ps, pb,
+                                         _stream()), "cmk_groupnorm_affine_multi")
+    return out
+
+
 def groupnorm_relu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-5) -> None:
     """In place on a dense NHWC tensor (fcos.py:182-186)."""
     lib = _lib.load()

@@ -95,6 +95,12 @@ int cmk_groupnorm_relu_nhwc(float* x, const float* gamma, const float* beta, dou
 int cmk_groupnorm_affine(const float* x, const float* gamma, const float* beta, double* ws, int ws_chunks,
                          int N, int HW, int C, int groups, float eps, float* out_scale, float* out_shift, void* stream);
 
+/* The same for up to 5 tensors (the FPN levels of one tower conv) in two launches; xs/out_scale/out_shift/HWs are HOST arrays
+ * of nlev entries; ws: nlev * N * groups * ws_chunks * 2 doubles. */
+int cmk_groupnorm_affine_multi(const float* const* xs, const int* HWs, int nlev, const float* gamma, const float* beta, double* ws,
+                               int ws_chunks, int N, int C, int groups, float eps, float* const* out_scale, float* const* out_shift,
+                               void* stream);
+
 /* ---- FCOS candidate selection + box decode (fcos_outputs.py:396-466) ------------------------------------------ */
 typedef struct {
     const float* logits;   /* (N, HW, C) */

@@ -221,3 +221,16 @@ def test_conv_fused_groupnorm_relu_input(dev, variant):
     _close(y.nchw(), ref)
     d[0].tune_wm = 4          # Winograd forms without the fused affine must refuse rather than ignore it
     assert _lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
+
+
+def test_groupnorm_affine_multi_level(dev):
+    shapes = [(100, 160), (13, 20), (7, 10), (1, 2)]
+    gamma = torch.rand(256, generator=torch.Generator().manual_seed(42)) + 0.5
+    beta = _rand((256,), 43, 0.1)
+    xs = [_rand((2, 256, h, w), 100 + i, 3.0) + 1.5 for i, (h, w) in enumerate(shapes)]
+    outs = ops.groupnorm_affine_multi([x.permute(0, 2, 3, 1).contiguous().to(dev) for x in xs], gamma.to(dev), beta.to(dev))
+    torch.cuda.synchronize()
+    for x, (sc, sh) in zip(xs, outs):
+        ref = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+        got = x * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+        _close(got, ref, 2e-5)
