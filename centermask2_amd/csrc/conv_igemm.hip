@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     }
 
     lds_dma_barrier();
-    float* ex = sV;                        // [wave 4][r 16][2][64 lanes] = 32 KiB
+    float2* ex = reinterpret_cast<float2*>(sV);     // [wave 4][r 16][64 lanes] x (dx 0,1) = 32 KiB
     float keep[16][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1104,16 +1104,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
             s0[i] = m0 + m1 + m2;
             s1[i] = m1 - m2 - m3;
         }
-        float send0, send1;
+        float2 send;
         if (fh == 0) {
             keep[r][0] = s0[0] + s0[1]; keep[r][1] = s1[0] + s1[1];
-            send0 = s0[1]; send1 = s1[1];
+            send = make_float2(s0[1], s1[1]);
         } else {
             keep[r][0] = -s0[0] - s0[1]; keep[r][1] = -s1[0] - s1[1];
-            send0 = s0[0]; send1 = s1[0];
+            send = make_float2(s0[0], s1[0]);
         }
-        ex[((wave * 16 + r) * 2 + 0) * 64 + lane] = send0;
-        ex[((wave * 16 + r) * 2 + 1) * 64 + lane] = send1;
+        ex[(wave * 16 + r) * 64 + lane] = send;
     }
     lds_dma_barrier();
     const int partner = wave ^ 2;
@@ -1122,19 +1121,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     const float sc = cvalid ? P.scale[co] : 0.f;
     const float sh = cvalid ? P.shift[co] : 0.f;
     const bool do_relu = co < a.relu_upto;
+    // accumulator row r of lane half hh is tile (ty, tx) = (r >> 2, (r & 3) + 4*hh): the row offset of a store is uniform per r,
+    // only the 8*hh column shift and the channel are per lane -> one lane base pointer, scalar offsets
+    const int ow_l = ow0 + 8 * hh;
+    float* ybase = P.y + (((long)n * H + oh0 + fh) * W + ow_l) * a.y_cs + a.y_co + co;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int t = (r & 3) + 8 * (r >> 2) + 4 * hh;        // tile index 0..31 (4 tile rows x 8 tile cols)
-        const int oh = oh0 + 2 * (t >> 3) + fh, ow = ow0 + 2 * (t & 7);
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            float yv = keep[r][dx] + ex[((partner * 16 + r) * 2 + dx) * 64 + lane];
-            if (cvalid && oh < H && ow + dx < W) {
-                float v = yv * sc + sh;
-                if (do_relu) v = fmaxf(v, 0.f);
-                P.y[(((long)n * H + oh) * W + ow + dx) * a.y_cs + a.y_co + co] = v;
-            }
-        }
+        const int ty = r >> 2, txr = r & 3;
+        const float2 other = ex[(partner * 16 + r) * 64 + lane];
+        const bool row_ok = cvalid && (oh0 + 2 * ty + fh < H);
+        float* yp = ybase + ((long)(2 * ty) * W + 2 * txr) * a.y_cs;
+        float v0 = (keep[r][0] + other.x) * sc + sh, v1 = (keep[r][1] + other.y) * sc + sh;
+        if (do_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        if (row_ok && ow_l + 2 * txr < W) yp[0] = v0;
+        if (row_ok && ow_l + 2 * txr + 1 < W) yp[a.y_cs] = v1;
     }
 }
 
