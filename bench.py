@@ -173,11 +173,18 @@ def main():
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  CMK_DIST_BACKEND=gloo + CMK_SHARE_GPU=1 exist only to rehearse the N>1 code path on a one-GPU box
+    # (every rank on cuda:0, gloo moving the records); the real runs use nccl = RCCL over xGMI, one device per rank.
+    backend = os.environ.get("CMK_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("CMK_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from centermask2_amd import synthetic as S
     model, sd = build(args.body, dev)
@@ -281,7 +288,7 @@ def main():
                            "launch": "hip-graph" if graph is not None else "eager",
                            "conv_variants": "measured table: {} problems loaded from {}, {} timed at start-up".format(
                                n_loaded, os.path.relpath(tune_file, ROOT), n_tuned - n_loaded) if not args.no_autotune else "library cost model",
-                           "collective": "RCCL all_gather of {} B/img records".format(rec.shape[1] * 4) if world > 1 else "none",
+                           "collective": "{} all_gather of {} B/img records".format("RCCL" if backend == "nccl" else backend, rec.shape[1] * 4) if world > 1 else "none",
                            "candidates_per_image": cand, "detections_per_image": dets,
                            "weights": "seeded random-init, reference state-dict keys"},
                 "roofline": roof,

@@ -159,3 +159,36 @@ def test_inference_with_pre_and_postprocess(dev, model):
         if len(inst):
             assert inst.pred_masks.dtype == torch.bool and tuple(inst.pred_masks.shape[1:]) == (im["height"], im["width"])
             assert float(inst.pred_boxes.tensor[:, 2].max()) <= im["width"] and float(inst.pred_boxes.tensor.min()) >= 0
+
+
+def test_zero_detections_and_capacity_overflow(dev):
+    """Edge cases of the detection tail: no score above 0.05 anywhere (empty Instances with the right field shapes, the ROI
+    heads run on zero valid slots), and more candidates than the workspace capacity (reported, never silently truncated)."""
+    from centermask2_amd import synthetic as S
+    from centermask2_amd.structures import FakeImageList
+    model, _ = build_gpu_model()
+    x = S.make_synthetic_images(2, 128, 160, seed0=99).to(dev)
+    images = FakeImageList(x, [(128, 160), (100, 150)])
+    head = model.proposal_generator.fcos_head
+    head.cls_logits.bias.data -= 30.0
+    head.invalidate_packed()
+    try:
+        res = model.inference(images, do_preprocess=False, do_postprocess=False)
+        torch.cuda.synchronize()
+        for inst in res:
+            assert len(inst) == 0
+            assert tuple(inst.pred_boxes.tensor.shape) == (0, 4) and tuple(inst.pred_masks.shape) == (0, 1, 28, 28)
+            assert tuple(inst.mask_scores.shape) == (0,) and inst.pred_classes.dtype == torch.int64
+    finally:
+        head.cls_logits.bias.data += 30.0
+        head.invalidate_packed()
+    head.cls_logits.bias.data += 8.0                      # nearly every (location, class) passes the threshold
+    head.invalidate_packed()
+    model.proposal_generator.candidate_capacity = 1024
+    try:
+        with pytest.raises(RuntimeError, match="capacity"):
+            model.inference(images, do_preprocess=False, do_postprocess=False)
+    finally:
+        head.cls_logits.bias.data -= 8.0
+        head.invalidate_packed()
+        model.proposal_generator.candidate_capacity = 131072
