@@ -938,7 +938,6 @@ constexpr int S_SU = 4 * 64 * 16;                  // one step = 4 frequencies
 constexpr int S_LDS_BYTES = (S_SH + S_SV + 2 * S_SU) * 4;
 constexpr int S_H_ITERS = (S_HALO * 4 + 255) / 256;
 
-template <int ABL>
 __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sH = smem;
@@ -1010,19 +1009,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
             }
         }
     };
-    // U tile of a step (4 freq x 64 co x 16 ci = 16 KiB, contiguous, already the swizzled LDS image): HBM -> registers TWO steps
-    // ahead (two register sets, alternating by step parity), registers -> LDS one step ahead.  One step of 16 MFMAs per wave is
-    // only ~0.5 us, less than an L2 round trip under load, so a one-step prefetch stalls every barrier.
-    f32x4 u_regs[2][4];
-    auto load_U = [&](int step, int set) {
+    auto glds_U = [&](int step, int buf) {          // step = chunk*4 + group; 4 freq x 64 co x 16 ci = 16 KiB contiguous
         const float* src = a.w + ((long)((step >> 2) * a.grid_y + by) * 16 + (step & 3) * 4) * (64 * 16);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) u_regs[set][it] = *reinterpret_cast<const f32x4*>(src + (it * 256 + tid) * 4);
-    };
-    auto store_U = [&](int set, int buf) {
         float* dst = sU + buf * S_SU;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(dst + (it * 256 + tid) * 4) = u_regs[set][it];
+        for (int it = 0; it < 4; ++it)
+            __builtin_amdgcn_global_load_lds(src + (it * 256 + tid) * 4, (lds_void*)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
     };
     const int t_half = tid >> 7, t_tile = (tid >> 2) & 31, t_q = tid & 3;
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
@@ -1056,7 +1048,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
 
     const int sw = (li >> 2) & 3;
     const int c0 = ((2 * hh) ^ sw) * 4, c1 = ((2 * hh + 1) ^ sw) * 4;
-    const int total_steps = nchunks * 4;
     const float* Abase = sV + ((fh * 8) * 32 + li) * 16;
     const int b_row = ((fh * 2) * 64 + ng * 32 + li) * 16;
 
@@ -1068,24 +1059,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     // Frequency rows are renumbered so that steps 0-1 use only "part 0" rows: step g streams {2g,2g+1} of each half, i.e.
     // local accumulators g*2+fl -> frequency index fh*8 + (g*2+fl); part 0 = local 0-3, part 1 = local 4-7.
     load_H(0);
-    load_U(0, 0);
-    if (total_steps > 1) load_U(1, 1);
+    glds_U(0, 0);
     store_H();
-    store_U(0, 0);
-    __syncthreads();
+    lds_dma_barrier();
     transform_part(0);
 
+    const int total_steps = nchunks * 4;
     for (int c = 0; c < nchunks; ++c) {
         const bool has_next_chunk = (c + 1 < nchunks);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int step = c * 4 + g;
-            __syncthreads();            // U[g & 1], V rows and halo written in earlier steps are visible; previous step is done
-            // registers of set (g+1)&1 hold U(step+1) (loaded during step-1): put them into the buffer step-1 just released,
-            // then refill set g&1 (its content, U(step), went to LDS one step ago) with U(step+2)
-            if (!(ABL & 2) && step + 1 < total_steps) store_U((g + 1) & 1, (g + 1) & 1);
-            if (!(ABL & 2) && step + 2 < total_steps) load_U(step + 2, g & 1);
-            if (!(ABL & 4) && g == 0 && has_next_chunk) load_H(c + 1);
+            lds_dma_barrier();          // U[g & 1] landed; V rows and halo written in earlier steps are visible; previous step is done
+            if (step + 1 < total_steps) glds_U(step + 1, (g + 1) & 1);
+            if (g == 0 && has_next_chunk) load_H(c + 1);
             const float* B = sU + (g & 1) * S_SU + b_row;
 #pragma unroll
             for (int fl = 0; fl < 2; ++fl) {
@@ -1094,22 +1081,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
                 f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + al * 32 * 16 + c1);
                 f32x4 b0 = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c0);
                 f32x4 b1 = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c1);
-                if (ABL & 8) {            // no MFMAs: keep the operand reads alive, fold them into the accumulator cheaply
-                    acc[al][0] += a0[0] + a1[0] + b0[0] + b1[0];
-                } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[al], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[al], 0, 0, 0);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[al], 0, 0, 0);
-                }
+                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[al], 0, 0, 0);
             }
-            if (!(ABL & 1) && g == 0) transform_part(1);                       // this chunk, rows used from step 2 on
-            if (!(ABL & 4) && g == 1 && has_next_chunk) store_H();             // everyone finished reading the old halo in step 0
-            if (!(ABL & 1) && g == 2 && has_next_chunk) transform_part(0);     // next chunk, rows last read in step 1
+            if (g == 0) transform_part(1);                       // this chunk, rows used from step 2 on
+            if (g == 1 && has_next_chunk) store_H();             // everyone finished reading the old halo in step 0
+            if (g == 2 && has_next_chunk) transform_part(0);     // next chunk, rows last read in step 1
         }
     }
 
-    __syncthreads();
+    lds_dma_barrier();
     float2* ex = reinterpret_cast<float2*>(sV);     // [wave 4][r 16][64 lanes] x (dx 0,1) = 32 KiB
     float keep[16][2];
 #pragma unroll
@@ -1131,7 +1114,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
         }
         ex[(wave * 16 + r) * 64 + lane] = send;
     }
-    __syncthreads();
+    lds_dma_barrier();
     const int partner = wave ^ 2;
     const int co = co0 + ng * 32 + li;
     const bool cvalid = co < a.Cout;
@@ -1155,8 +1138,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     }
 }
 
-static int g_wino_ablation = 0;
-
 static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1166,11 +1147,7 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
-        const void* abl[] = {(const void*)conv_wino4s_kernel<1>, (const void*)conv_wino4s_kernel<2>, (const void*)conv_wino4s_kernel<4>,
-                             (const void*)conv_wino4s_kernel<7>, (const void*)conv_wino4s_kernel<8>};
-        for (const void* k : abl)
-            if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
         if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -1183,16 +1160,8 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
         blocks += p.N * p.tiles_h * p.tiles_w;
     }
     a.grid_y = cdiv(a.Cout, 64);
-    if (waves8 == 3) {
-        switch (g_wino_ablation) {      // diagnostic builds of the same kernel with one cost removed (tools/ablate_wino.py); 0 = product
-            case 1: hipLaunchKernelGGL(conv_wino4s_kernel<1>, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a); break;
-            case 2: hipLaunchKernelGGL(conv_wino4s_kernel<2>, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a); break;
-            case 4: hipLaunchKernelGGL(conv_wino4s_kernel<4>, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a); break;
-            case 7: hipLaunchKernelGGL(conv_wino4s_kernel<7>, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a); break;
-            case 8: hipLaunchKernelGGL(conv_wino4s_kernel<8>, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a); break;
-            default: hipLaunchKernelGGL(conv_wino4s_kernel<0>, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a);
-        }
-    }
+    if (waves8 == 3)
+        hipLaunchKernelGGL(conv_wino4s_kernel, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a);
     else if (waves8 == 2)
         hipLaunchKernelGGL(conv_wino8b_kernel, dim3(blocks * a.grid_y), dim3(512), W2_LDS_BYTES, st, a);
     else if (waves8)
@@ -1398,9 +1367,6 @@ extern "C" int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize) {
     int64_t nch = (Cin + 15) / 16;
     return taps * nch * cmk_conv_cout_pad(Cout) * 16;
 }
-
-// Diagnostic hook (not declared in cmk.h): selects an ablated build of the Winograd kernel for timing experiments.
-extern "C" void cmk_debug_wino_ablation(int mask) { cmk::g_wino_ablation = mask; }
 
 extern "C" int64_t cmk_wino_packed_floats(int Cout, int Cin) {
     return (int64_t)((Cin + 15) / 16) * ((Cout + 63) / 64) * 16 * 64 * 16;
