@@ -1064,31 +1064,60 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     lds_dma_barrier();
     transform_part(0);
 
+    // Branch-free loop body: "next" indices are clamped to the last chunk/step instead of being guarded (the redundant tail work
+    // reloads data nobody reads), so every step is ONE basic block and the scheduler can interleave the staging / transform
+    // instructions between the MFMAs.  An in-order wave cannot issue anything behind a block of 16 back-to-back MFMAs until the
+    // last one has been accepted by the pipe (~1-2k cycles with the pipe shared by two waves), so without the interleave the
+    // "shadowed" work was in fact serialised behind the MFMA block; the sched_group_barrier sequence below spreads it.
     const int total_steps = nchunks * 4;
     for (int c = 0; c < nchunks; ++c) {
-        const bool has_next_chunk = (c + 1 < nchunks);
+        const int cn = min(c + 1, nchunks - 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int step = c * 4 + g;
             lds_dma_barrier();          // U[g & 1] landed; V rows and halo written in earlier steps are visible; previous step is done
-            if (step + 1 < total_steps) glds_U(step + 1, (g + 1) & 1);
-            if (g == 0 && has_next_chunk) load_H(c + 1);
+            glds_U(min(step + 1, total_steps - 1), (g + 1) & 1);
+            if (g == 0) load_H(cn);
             const float* B = sU + (g & 1) * S_SU + b_row;
+            f32x4 a0[2], a1[2], b0[2], b1[2];
 #pragma unroll
             for (int fl = 0; fl < 2; ++fl) {
                 const int al = g * 2 + fl;
-                f32x4 a0 = *reinterpret_cast<const f32x4*>(Abase + al * 32 * 16 + c0);
-                f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + al * 32 * 16 + c1);
-                f32x4 b0 = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c0);
-                f32x4 b1 = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c1);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[al], 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[al], 0, 0, 0);
+                a0[fl] = *reinterpret_cast<const f32x4*>(Abase + al * 32 * 16 + c0);
+                a1[fl] = *reinterpret_cast<const f32x4*>(Abase + al * 32 * 16 + c1);
+                b0[fl] = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c0);
+                b1[fl] = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c1);
             }
-            if (g == 0) transform_part(1);                       // this chunk, rows used from step 2 on
-            if (g == 1 && has_next_chunk) store_H();             // everyone finished reading the old halo in step 0
-            if (g == 2 && has_next_chunk) transform_part(0);     // next chunk, rows last read in step 1
+#pragma unroll
+            for (int fl = 0; fl < 2; ++fl) {
+                const int al = g * 2 + fl;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[fl][s], b0[fl][s], acc[al], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[fl][s], b1[fl][s], acc[al], 0, 0, 0);
+            }
+            if (g == 0) transform_part(1);       // this chunk, rows used from step 2 on
+            if (g == 1) store_H();               // everyone finished reading the old halo in step 0
+            if (g == 2) transform_part(0);       // next chunk (clamped), rows last read in step 1
+            // interleave: the 8 operand reads first, then per pair of MFMAs a slice of the other work
+            // (masks: VALU 0x2, MFMA 0x8, DS read 0x100, DS write 0x200)
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            if (g == 0 || g == 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // 12 patch reads
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 4 V writes (the surplus groups stay empty)
+                }
+            } else if (g == 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 3 halo writes
+                }
+            }
         }
     }
 
