@@ -192,3 +192,34 @@ def test_average_precision_known_answers():
     gm = [dict(boxes=gt[0]["boxes"], classes=torch.tensor([1, 1]), masks=m)]
     pm = [dict(boxes=gt[0]["boxes"], classes=torch.tensor([1, 1]), masks=m.clone(), scores=torch.tensor([0.1, 0.9]), mask_scores=torch.tensor([0.9, 0.1]))]
     assert average_precision(pm, gm, "mask") == pytest.approx(1.0)
+
+
+def test_wire_formats_bin_and_coco_json(tmp_path):
+    import numpy as np
+    from centermask2_amd import wire
+    from centermask2_amd.structures import Boxes, Instances
+    g = torch.Generator().manual_seed(3)
+    n = 5
+    t6 = (torch.rand((n, 2), generator=g), torch.rand(n, generator=g), torch.rand((n, 4), generator=g) * 100,
+          torch.randint(0, 80, (n,), generator=g), torch.rand((n, 1, 28, 28), generator=g), torch.rand(n, generator=g))
+    paths = wire.to_bin(t6, str(tmp_path / "000000000139"))
+    assert [os.path.getsize(p) for p in paths] == [n * 8, n * 4, n * 16, n * 8, n * 784 * 4, n * 4]      # dtypes of postprocess_bin_outputs.py:37
+    back = wire.from_bin(str(tmp_path / "000000000139"))
+    assert all(torch.equal(a, b) for a, b in zip(back, t6)) and back[3].dtype == torch.int64
+    # RLE: round trip on random, empty, full and single-pixel masks; column-major run order; delta coding with negative deltas
+    for m in (torch.rand((37, 53), generator=g) > 0.5, torch.zeros((4, 6), dtype=torch.bool), torch.ones((4, 6), dtype=torch.bool),
+              torch.tensor([[0, 1], [0, 0]], dtype=torch.bool)):
+        rle = wire.rle_encode(m)
+        assert rle["size"] == list(m.shape) and isinstance(rle["counts"], str)
+        assert np.array_equal(wire.rle_decode(rle), m.numpy())
+    assert wire.rle_counts(np.array([[0, 1], [0, 0]])) == [2, 1, 1]               # column-major: 0,0,1,0
+    assert wire.rle_counts(np.ones((2, 2))) == [0, 4]
+    big = [0, 5000, 3, 100000, 2, 7]
+    assert wire.rle_from_string(wire.rle_to_string(big)) == big
+    inst = Instances((37, 53), pred_boxes=Boxes(torch.tensor([[1., 2., 11., 22.], [0., 0., 5., 5.]])), scores=torch.tensor([0.9, 0.8]),
+                     pred_classes=torch.tensor([3, 7]), pred_masks=torch.rand((2, 37, 53), generator=g) > 0.5, mask_scores=torch.tensor([0.5, 0.6]))
+    js = wire.instances_to_coco_json(inst, 139)
+    assert js[0]["bbox"] == [1.0, 2.0, 10.0, 20.0] and js[0]["category_id"] == 3 and js[1]["mask_score"] == pytest.approx(0.6)
+    seg = wire.segm_results_ranked_by_mask_score(js)
+    assert "bbox" not in seg[0] and seg[0]["score"] == pytest.approx(0.5) and "mask_score" not in seg[0] and js[0]["score"] == pytest.approx(0.9)
+    assert wire.instances_to_coco_json(inst[torch.zeros(2, dtype=torch.bool)], 1) == []
