@@ -65,8 +65,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 // MaxPool2d(3, 2, ceil_mode=True), no padding (vovnet.py:349-350).  One lane = one output pixel x 4 channels.
 // ---------------------------------------------------------------------------------------------------------------
+// `gate` (optional, N*C, all >= 0): the eSE channel gate of the producer block applied after the max — max(x*g) == g*max(x)
+// for g >= 0, so stage 2's eSE scale pass (whose output nobody else reads) folds into the pool.
 __global__ __launch_bounds__(256) void maxpool3_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y,
-                                                      int y_cs, int y_co, int N, int H, int W, int Ho, int Wo, int C4) {
+                                                      int y_cs, int y_co, int N, int H, int W, int Ho, int Wo, int C4,
+                                                      const float* __restrict__ gate) {
     long total = (long)N * Ho * Wo * C4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         int c4 = (int)(i % C4);
@@ -85,6 +88,10 @@ __global__ __launch_bounds__(256) void maxpool3_kernel(const float* __restrict__
                     m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
                 }
             }
+        if (gate) {
+            f32x4 g = *reinterpret_cast<const f32x4*>(gate + ((long)n * C4 + c4) * 4);
+            m.x *= g.x; m.y *= g.y; m.z *= g.z; m.w *= g.w;
+        }
         *reinterpret_cast<f32x4*>(y + p * y_cs + y_co + c4 * 4) = m;
     }
 }
@@ -360,7 +367,7 @@ extern "C" int cmk_stem_conv_nchw3(const float* x, const float* w, const float* 
 }
 
 extern "C" int cmk_maxpool3x3s2_ceil_nhwc(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int H, int W, int C,
-                                          void* stream) {
+                                          const float* gate, void* stream) {
     if (!x || !y) return fail(CMK_EINVAL, "maxpool: null pointer%s", "");
     if ((C & 3) || (x_cs & 3) || (x_co & 3) || (y_cs & 3) || (y_co & 3)) return fail(CMK_EINVAL, "maxpool: channels must be multiples of 4%s", "");
     if (H < 3 || W < 3) return fail(CMK_EINVAL, "maxpool: input smaller than the window%s", "");
@@ -369,7 +376,7 @@ extern "C" int cmk_maxpool3x3s2_ceil_nhwc(const float* x, int x_cs, int x_co, fl
     if ((Wo - 1) * 2 >= W) --Wo;
     long total = (long)N * Ho * Wo * (C >> 2);
     hipLaunchKernelGGL(maxpool3_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, y, y_cs, y_co, N, H, W,
-                       Ho, Wo, C >> 2);
+                       Ho, Wo, C >> 2, gate);
     return check_launch("maxpool3");
 }
 

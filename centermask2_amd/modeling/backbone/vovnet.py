@@ -155,6 +155,7 @@ class VoVNet(Backbone):
         s2 = ops.conv_out(s1, P["stem_2"], relu=True)
         n = x.shape[0]
         prev = None        # dense output View of the previous stage
+        prev_gate = None   # eSE gate still to be applied to `prev` (folded into the next max pool)
         for sname in self.stage_names:
             blocks = getattr(self, sname).blocks()
             if sname == "stage2":
@@ -171,7 +172,8 @@ class VoVNet(Backbone):
                 else:
                     ops.conv2d(s2, P["stem_3"], inp, relu=True)
             else:
-                ops.maxpool3x3s2_ceil(prev, inp)                     # vovnet.py:349-350
+                ops.maxpool3x3s2_ceil(prev, inp, gate=prev_gate)     # vovnet.py:349-350 (+ the pending eSE scale, see below)
+                prev_gate = None
             for b, blk in enumerate(blocks):
                 mn = blk.module_name
                 src, off = inp, blk.in_ch
@@ -187,7 +189,13 @@ class VoVNet(Backbone):
                     nxt = None
                     out = View(torch.empty((n, h, w, blk.concat_ch), dtype=torch.float32, device=dev))
                 fw, fb = P[mn + "_ese"]
-                ops.ese(xt, fw, fb, out, identity=inp if blk.identity else None)   # eSE then identity add (:327-330)
+                if nxt is None and not blk.identity and sname not in self._out_features and sname != self.stage_names[-1]:
+                    # nobody but the next stage's max pool reads this output: max(x*g) == g*max(x) for the non-negative
+                    # hsigmoid gate, so the scale pass (a full read+write of the largest map) is folded into the pool
+                    prev_gate = ops.ese_gate(xt, fw, fb)
+                    out = xt
+                else:
+                    ops.ese(xt, fw, fb, out, identity=inp if blk.identity else None)   # eSE then identity add (:327-330)
                 if nxt is not None:
                     cat, inp = nxt, out
             prev = out

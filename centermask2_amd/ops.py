@@ -307,7 +307,7 @@ def stem_conv(x_nchw: torch.Tensor, w27: torch.Tensor, scale: torch.Tensor, shif
     return View(y)
 
 
-def maxpool3x3s2_ceil(x: View, y: Optional[View] = None) -> View:
+def maxpool3x3s2_ceil(x: View, y: Optional[View] = None, gate: Optional[torch.Tensor] = None) -> View:
     lib = _lib.load()
     n, h, w = x.nhw
     ho = -(-(h - 3) // 2) + 1
@@ -319,9 +319,23 @@ def maxpool3x3s2_ceil(x: View, y: Optional[View] = None) -> View:
     if y is None:
         y = View(torch.empty((n, ho, wo, x.c), dtype=torch.float32, device=x.t.device))
     assert tuple(y.t.shape[:3]) == (n, ho, wo) and y.c == x.c
-    check(lib.cmk_maxpool3x3s2_ceil_nhwc(x.t.data_ptr(), x.cs, x.co, y.t.data_ptr(), y.cs, y.co, n, h, w, x.c, _stream()),
+    check(lib.cmk_maxpool3x3s2_ceil_nhwc(x.t.data_ptr(), x.cs, x.co, y.t.data_ptr(), y.cs, y.co, n, h, w, x.c,
+                                         gate.data_ptr() if gate is not None else None, _stream()),
           "cmk_maxpool3x3s2_ceil_nhwc")
     return y
+
+
+def ese_gate(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.Tensor:
+    """gate (N,C) = hsigmoid(fc(mean_HW(x)))   (vovnet.py:255-259)."""
+    lib = _lib.load()
+    n, h, w = x.nhw
+    hw, c = h * w, x.c
+    chunks = max(1, min(256, hw // 256))
+    ws = torch.empty((n, chunks, c), dtype=torch.float32, device=x.t.device)
+    gate = torch.empty((n, c), dtype=torch.float32, device=x.t.device)
+    check(lib.cmk_ese_gate(x.t.data_ptr(), x.cs, x.co, fc_w.data_ptr(), fc_b.data_ptr(), gate.data_ptr(), ws.data_ptr(), chunks,
+                           n, hw, c, _stream()), "cmk_ese_gate")
+    return gate
 
 
 def ese(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor, y: View, identity: Optional[View] = None) -> None:
@@ -329,7 +343,7 @@ def ese(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor, y: View, identity: Opti
     lib = _lib.load()
     n, h, w = x.nhw
     hw, c = h * w, x.c
-    chunks = max(1, min(64, hw // 256))
+    chunks = max(1, min(256, hw // 256))
     ws = torch.empty((n, chunks, c), dtype=torch.float32, device=x.t.device)
     gate = torch.empty((n, c), dtype=torch.float32, device=x.t.device)
     check(lib.cmk_ese_gate(x.t.data_ptr(), x.cs, x.co, fc_w.data_ptr(), fc_b.data_ptr(), gate.data_ptr(), ws.data_ptr(), chunks,

@@ -75,8 +75,9 @@ int cmk_stem_conv_nchw3(const float* x, const float* w /* [27][Cout] */, const f
                         float* y, int N, int H, int W, int Cout, void* stream);
 
 /* ---- max pool k3 s2 ceil_mode, no padding (vovnet.py:349-350); k2 s2 (maskiou_head.py:93,108) ----------------- */
+/* gate: optional (N*C) non-negative channel gate applied after the max (the eSE scale of the producer block, folded in). */
 int cmk_maxpool3x3s2_ceil_nhwc(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co,
-                               int N, int H, int W, int C, void* stream);
+                               int N, int H, int W, int C, const float* gate, void* stream);
 
 /* ---- eSE (vovnet.py:247-260): gate = relu6(W * mean_HW(x) + b + 3) / 6 ; y = x * gate (+ identity) ------------
  * ws: N * ese_chunks * C floats of workspace for the two-stage mean.                                        */

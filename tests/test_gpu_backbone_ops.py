@@ -234,3 +234,12 @@ def test_groupnorm_affine_multi_level(dev):
         ref = F.group_norm(x, 32, gamma, beta, eps=1e-5)
         got = x * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
         _close(got, ref, 2e-5)
+
+
+def test_maxpool_with_folded_ese_gate(dev):
+    x = _rand((2, 64, 21, 30), 111)
+    gate = torch.rand((2, 64), generator=torch.Generator().manual_seed(112))
+    ref = F.max_pool2d(x * gate[:, :, None, None], 3, 2, ceil_mode=True)
+    y = ops.maxpool3x3s2_ceil(ops.as_view(x.to(dev)), gate=gate.to(dev))
+    torch.cuda.synchronize()
+    _close(y.nchw(), ref, 1e-6)
