@@ -1009,28 +1009,37 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
             }
         }
     };
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);     // scalar, so the LDS-DMA base (M0) needs no per-instruction readfirstlane
     auto glds_U = [&](int step, int buf) {          // step = chunk*4 + group; 4 freq x 64 co x 16 ci = 16 KiB contiguous
         const float* src = a.w + ((long)((step >> 2) * a.grid_y + by) * 16 + (step & 3) * 4) * (64 * 16);
         float* dst = sU + buf * S_SU;
 #pragma unroll
         for (int it = 0; it < 4; ++it)
-            __builtin_amdgcn_global_load_lds(src + (it * 256 + tid) * 4, (lds_void*)(dst + (it * 256 + wave * 64) * 4), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src + (it * 256 + tid) * 4, (lds_void*)(dst + (it * 256 + uwave * 64) * 4), 16, 0, 0);
     };
     const int t_half = tid >> 7, t_tile = (tid >> 2) & 31, t_q = tid & 3;
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
     const int v_chunk = (t_q ^ ((t_tile >> 2) & 3)) * 4;
     // Input transform of one frequency row pair: part 0 -> rows {0, 2} (frequencies 0-3 / 8-11, used by steps 0-1),
     // part 1 -> rows {1, 3} (frequencies 4-7 / 12-15, used by steps 2-3).  Thread half h2 owns rows {2*h2, 2*h2+1}.
+    // Row ii of a thread half is p + sg*q of two patch rows (B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]):
+    //   half 0: row 0 = d0 - d2, row 1 = d1 + d2;   half 1: row 2 = d2 - d1, row 3 = d1 - d3.
+    // The half is wave-uniform, so (p row, q row, sign) are scalars: 8 loads + 16 FMAs per part, no select of two variants.
+    const int uhalf = __builtin_amdgcn_readfirstlane(t_half);
+    const int prow0 = uhalf ? 2 : 0, qrow0 = uhalf ? 1 : 2;      // part 0 (ii = 0): sign -1 for both halves
+    const int prow1 = 1, qrow1 = uhalf ? 3 : 2;                  // part 1 (ii = 1)
+    const float sg1 = uhalf ? -1.0f : 1.0f;
     auto transform_part = [&](int ii) {
-        const float* src = sH + ((2 * t_ty + t_half) * 18 + 2 * t_tx) * PST + t_q * 4;
+        const float* src = sH + ((2 * t_ty) * 18 + 2 * t_tx) * PST + t_q * 4;
+        const float* ps = src + (ii == 0 ? prow0 : prow1) * 18 * PST;
+        const float* qs = src + (ii == 0 ? qrow0 : qrow1) * 18 * PST;
+        const float sg = ii == 0 ? -1.0f : sg1;
         f32x4 x[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x4 da = *reinterpret_cast<const f32x4*>(src + (0 * 18 + j) * PST);
-            f32x4 db = *reinterpret_cast<const f32x4*>(src + (1 * 18 + j) * PST);
-            f32x4 dc = *reinterpret_cast<const f32x4*>(src + (2 * 18 + j) * PST);
-            if (t_half == 0) x[j] = ii == 0 ? (da - dc) : (db + dc);     // rows 0,1 of B^T d from d0,d1,d2
-            else             x[j] = ii == 0 ? (db - da) : (da - dc);     // rows 2,3 of B^T d from d1,d2,d3
+            f32x4 pv = *reinterpret_cast<const f32x4*>(ps + j * PST);
+            f32x4 qv = *reinterpret_cast<const f32x4*>(qs + j * PST);
+            x[j] = pv + sg * qv;
         }
         f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
         float* dst = sV + (((2 * t_half + ii) * 4) * 32 + t_tile) * 16 + v_chunk;
@@ -1088,14 +1097,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
                 b0[fl] = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c0);
                 b1[fl] = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c1);
             }
+            // consecutive MFMAs go to different accumulators (no back-to-back dependent pair)
 #pragma unroll
-            for (int fl = 0; fl < 2; ++fl) {
-                const int al = g * 2 + fl;
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[fl][s], b0[fl][s], acc[al], 0, 0, 0);
+                for (int fl = 0; fl < 2; ++fl)
+                    acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[fl][s], b0[fl][s], acc[g * 2 + fl], 0, 0, 0);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[fl][s], b1[fl][s], acc[al], 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl)
+                    acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[fl][s], b1[fl][s], acc[g * 2 + fl], 0, 0, 0);
             if (g == 0) transform_part(1);       // this chunk, rows used from step 2 on
             if (g == 1) store_H();               // everyone finished reading the old halo in step 0
             if (g == 2) transform_part(0);       // next chunk (clamped), rows last read in step 1
@@ -1106,7 +1118,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // 12 patch reads
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 8 patch reads
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 4 V writes (the surplus groups stay empty)
                 }
