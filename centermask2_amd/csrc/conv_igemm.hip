@@ -1009,13 +1009,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
             }
         }
     };
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);     // scalar, so the LDS-DMA base (M0) needs no per-instruction readfirstlane
-    auto glds_U = [&](int step, int buf) {          // step = chunk*4 + group; 4 freq x 64 co x 16 ci = 16 KiB contiguous
-        const float* src = a.w + ((long)((step >> 2) * a.grid_y + by) * 16 + (step & 3) * 4) * (64 * 16);
-        float* dst = sU + buf * S_SU;
+    // LDS-DMA of a step's U image (4 freq x 64 co x 16 ci = 16 KiB, contiguous in HBM and in LDS): each wave copies its own
+    // contiguous 4 KiB with 4 instructions of 1 KiB, so a thread needs ONE 64-bit source address per step (the 4 pieces are
+    // immediate offsets 0/1/2/3 KiB) and the LDS base (M0) is scalar arithmetic on the wave index.
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const float* u_thread = a.w + (long)by * 16 * (64 * 16) + uwave * 1024 + lane * 4;
+    const long u_chunk_stride = (long)a.grid_y * 16 * (64 * 16);
+    auto glds_U = [&](int step, int buf) {          // step = chunk*4 + group
+        const float* src = u_thread + (step >> 2) * u_chunk_stride + (step & 3) * (4 * 64 * 16);
+        float* dst = sU + buf * S_SU + uwave * 1024;
 #pragma unroll
         for (int it = 0; it < 4; ++it)
-            __builtin_amdgcn_global_load_lds(src + (it * 256 + tid) * 4, (lds_void*)(dst + (it * 256 + uwave * 64) * 4), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src + it * 256, (lds_void*)(dst + it * 256), 16, 0, 0);
     };
     const int t_half = tid >> 7, t_tile = (tid >> 2) & 31, t_q = tid & 3;
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
