@@ -343,191 +343,6 @@ constexpr int W_SH = W_HALO * PST;            // floats
 constexpr int W_SV = 16 * 64 * PST;
 constexpr int W_SU = 4 * 64 * PST;            // one group of 4 frequencies
 constexpr int W_LDS_BYTES = (W_SH + W_SV + 2 * W_SU) * 4;
-constexpr int W_A_ITERS = (W_HALO * 4 + 255) / 256;
-
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sH = smem;
-    float* sV = smem + W_SH;
-    float* sU = smem + W_SH + W_SV;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int hh = lane >> 5, li = lane & 31;
-    const int mg = wave >> 1, ng = wave & 1;
-
-    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < MAXP; ++i)
-        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
-    const ConvProblem& P = a.p[pi];
-    const int H = P.H, W = P.W;
-    const int tile = bx - P.tile_begin;
-    const int tw = tile % P.tiles_w;
-    const int t2 = tile / P.tiles_w;
-    const int th = t2 % P.tiles_h;
-    const int n = t2 / P.tiles_h;
-    const int oh0 = th * 16, ow0 = tw * 16;
-    const int co0 = by * 64;
-    const int nchunks = a.Cin >> 4;
-
-    // halo staging descriptors (clamped address + validity bit, as in the direct kernel)
-    const float* xin = P.x + (long)n * H * W * a.x_cs + a.x_co;
-    long g_off[W_A_ITERS];
-    unsigned ok = 0;
-#pragma unroll
-    for (int it = 0; it < W_A_ITERS; ++it) {
-        int idx = it * 256 + tid;
-        int pix = idx >> 2, q = idx & 3;
-        long off = 0;
-        if (idx < W_HALO * 4) {
-            int hr = pix / 18, hc = pix - hr * 18;
-            int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
-            if (ih >= 0 && ih < H && iw >= 0 && iw < W) { off = ((long)ih * W + iw) * a.x_cs + q * 4; ok |= 1u << it; }
-        }
-        g_off[it] = off;
-    }
-    f32x4 h_stage[W_A_ITERS];
-    f32x4 u_stage[4];
-    auto load_H = [&](int chunk) {
-#pragma unroll
-        for (int it = 0; it < W_A_ITERS; ++it) h_stage[it] = *reinterpret_cast<const f32x4*>(xin + g_off[it] + chunk * 16);
-    };
-    auto store_H = [&]() {
-#pragma unroll
-        for (int it = 0; it < W_A_ITERS; ++it) {
-            int idx = it * 256 + tid;
-            if ((it + 1) * 256 <= W_HALO * 4 || idx < W_HALO * 4) {
-                f32x4 v = h_stage[it];
-                const bool k = (ok >> it) & 1u;
-                v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
-                *reinterpret_cast<f32x4*>(sH + (idx >> 2) * PST + (idx & 3) * 4) = v;
-            }
-        }
-    };
-    // U layout in HBM: [chunk][ntile][16 freq][64 co][16 ci]
-    auto load_U = [&](int step) {          // step = chunk*4 + group
-        const float* src = a.w + ((long)((step >> 2) * a.grid_y + by) * 16 + (step & 3) * 4) * (64 * 16);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) u_stage[it] = *reinterpret_cast<const f32x4*>(src + (it * 256 + tid) * 4);
-    };
-    auto store_U = [&](int buf) {
-        float* dst = sU + buf * W_SU;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int idx = it * 256 + tid;
-            int row = idx >> 2;           // HBM holds the swizzled image: physical chunk p carries logical chunk p ^ ((co>>2)&3)
-            *reinterpret_cast<f32x4*>(dst + row * PST + ((idx & 3) ^ ((row >> 2) & 3)) * 4) = u_stage[it];
-        }
-    };
-    // input transform: thread = (tile, channel quad); V = B^T d B
-    const int t_tile = tid >> 2, t_q = tid & 3;
-    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-    auto transform = [&]() {
-        const float* src = sH + ((2 * t_ty) * 18 + 2 * t_tx) * PST + t_q * 4;
-        f32x4 x[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {     // columns of the patch: apply B^T down the rows
-            f32x4 d0 = *reinterpret_cast<const f32x4*>(src + (0 * 18 + j) * PST);
-            f32x4 d1 = *reinterpret_cast<const f32x4*>(src + (1 * 18 + j) * PST);
-            f32x4 d2 = *reinterpret_cast<const f32x4*>(src + (2 * 18 + j) * PST);
-            f32x4 d3 = *reinterpret_cast<const f32x4*>(src + (3 * 18 + j) * PST);
-            x[0][j] = d0 - d2; x[1][j] = d1 + d2; x[2][j] = d2 - d1; x[3][j] = d1 - d3;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v0 = x[i][0] - x[i][2], v1 = x[i][1] + x[i][2], v2 = x[i][2] - x[i][1], v3 = x[i][1] - x[i][3];
-            float* dst = sV + ((i * 4) * 64 + t_tile) * PST + t_q * 4;
-            *reinterpret_cast<f32x4*>(dst + 0 * 64 * PST) = v0;
-            *reinterpret_cast<f32x4*>(dst + 1 * 64 * PST) = v1;
-            *reinterpret_cast<f32x4*>(dst + 2 * 64 * PST) = v2;
-            *reinterpret_cast<f32x4*>(dst + 3 * 64 * PST) = v3;
-        }
-    };
-
-    f32x16 acc[16];
-#pragma unroll
-    for (int f = 0; f < 16; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-
-    const float* Abase = sV + (mg * 32 + li) * PST + hh * 8;
-    const int b_off = (ng * 32 + li) * PST + hh * 8;
-
-    load_H(0);
-    load_U(0);
-    store_H();
-    store_U(0);
-    __syncthreads();
-    transform();
-
-    const int total_steps = nchunks * 4;
-    for (int c = 0; c < nchunks; ++c) {
-        const bool has_next_chunk = (c + 1 < nchunks);
-        if (has_next_chunk) load_H(c + 1);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int step = c * 4 + g;
-            const bool has_next = (step + 1 < total_steps);
-            if (has_next) load_U(step + 1);
-            __syncthreads();          // V (g == 0) and U[g & 1] visible; everyone is done with the previous step
-            const float* B = sU + (g & 1) * W_SU + b_off;
-#pragma unroll
-            for (int fl = 0; fl < 4; ++fl) {
-                const int f = (fl >> 1) * 8 + g * 2 + (fl & 1);     // U is packed in this step order (shared with the 8-wave kernel)
-                f32x4 a0 = *reinterpret_cast<const f32x4*>(Abase + f * 64 * PST);
-                f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + f * 64 * PST + 4);
-                f32x4 b0 = *reinterpret_cast<const f32x4*>(B + fl * 64 * PST);
-                f32x4 b1 = *reinterpret_cast<const f32x4*>(B + fl * 64 * PST + 4);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[f], 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[f], 0, 0, 0);
-            }
-            if (has_next) store_U((g + 1) & 1);
-        }
-        if (has_next_chunk) {
-            __syncthreads();          // every wave is done reading V of this chunk (and the halo was consumed before)
-            store_H();
-            __syncthreads();
-            transform();
-        }
-    }
-
-    // ---- output transform (per lane, registers only) + epilogue ------------------------------------------------------
-    const int co = co0 + ng * 32 + li;
-    const bool cvalid = co < a.Cout;
-    const float sc = cvalid ? P.scale[co] : 0.f;
-    const float sh = cvalid ? P.shift[co] : 0.f;
-    const bool do_relu = co < a.relu_upto;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int t = mg * 32 + row;
-        const int oh = oh0 + 2 * (t >> 3), ow = ow0 + 2 * (t & 7);
-        float s0[4], s1[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {     // M A : combine the 4 columns of row i
-            float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r], m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
-            s0[i] = m0 + m1 + m2;
-            s1[i] = m1 - m2 - m3;
-        }
-        float y[2][2];
-        y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s1[0] + s1[1] + s1[2];
-        y[1][0] = s0[1] - s0[2] - s0[3]; y[1][1] = s1[1] - s1[2] - s1[3];
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                if (cvalid && oh + dy < H && ow + dx < W) {
-                    float v = y[dy][dx] * sc + sh;
-                    if (do_relu) v = fmaxf(v, 0.f);
-                    P.y[(((long)n * H + oh + dy) * W + ow + dx) * a.y_cs + a.y_co + co] = v;
-                }
-            }
-    }
-}
 
 // 8-wave form of the Winograd kernel: same workgroup tile and LDS image, but two waves per SIMD, each owning 8 of the 16
 // frequency accumulators of its (32 tiles x 32 couts) sub-tile (fh = frequency half = rows {0,1} or {2,3} of the 4x4
@@ -732,14 +547,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvArgs a) {
 }
 
 
-// Third form: the halo tile is not staged at all.  Every thread fetches its 3x4 input patch (the rows its half of the
-// input transform needs) straight from global memory/L1 into registers one chunk ahead, transforms it in registers and
-// writes only V to LDS.  The weights go HBM -> LDS directly (global_load_lds, no VGPR staging, 8 frequencies per step):
-// the packed U image in HBM is already the LDS image (64-byte rows, 16-byte chunks XOR-swizzled by (co>>2)&3 so that the
-// ds_read_b128 operand reads are conflict-free without padding).  A chunk costs 3 barriers (2 steps + 1 hand-over).
-constexpr int W2_SU = 8 * 64 * 16;                           // floats per step: 8 frequencies, unpadded
-constexpr int W2_LDS_BYTES = (W_SV + 2 * W2_SU) * 4;         // 80 KiB + 64 KiB
-
 typedef __attribute__((address_space(3))) void lds_void;
 
 // Barrier for kernels with global_load_lds in flight.  hipcc does not reliably put the `s_waitcnt vmcnt(0)` in front of a
@@ -748,182 +555,6 @@ typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ void lds_dma_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-}
-
-__global__ __launch_bounds__(512, 2) void conv_wino8b_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sV = smem;
-    float* sU = smem + W_SV;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int hh = lane >> 5, li = lane & 31;
-    const int fh = wave >> 2, mg = (wave >> 1) & 1, ng = wave & 1;
-
-    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < MAXP; ++i)
-        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
-    const ConvProblem& P = a.p[pi];
-    const int H = P.H, W = P.W;
-    const int tile = bx - P.tile_begin;
-    const int tw = tile % P.tiles_w;
-    const int t2 = tile / P.tiles_w;
-    const int th = t2 % P.tiles_h;
-    const int n = t2 / P.tiles_h;
-    const int oh0 = th * 16, ow0 = tw * 16;
-    const int co0 = by * 64;
-    const int nchunks = a.Cin >> 4;
-
-    // my patch: rows (2*ty + half) .. +2, cols 2*tx .. +3 of the halo frame (origin oh0-1, ow0-1), channel quad q
-    const int t_half = tid >> 8, t_tile = (tid >> 2) & 63, t_q = tid & 3;
-    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-    const float* xin = P.x + (long)n * H * W * a.x_cs + a.x_co + t_q * 4;
-    // addresses are row offset + column offset with each coordinate clamped into the image (always a valid address);
-    // `ok` remembers which of the 12 elements are real, the others are zero padding
-    int row_off[3], col_off[4];
-    unsigned ok = 0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        int ih = oh0 - 1 + 2 * t_ty + t_half + r;
-        row_off[r] = min(max(ih, 0), H - 1) * W * a.x_cs;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int iw = ow0 - 1 + 2 * t_tx + j;
-            ok |= ((ih >= 0 && ih < H && iw >= 0 && iw < W) ? 1u : 0u) << (r * 4 + j);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) col_off[j] = min(max(ow0 - 1 + 2 * t_tx + j, 0), W - 1) * a.x_cs;
-    f32x4 patch[12];
-    auto load_P = [&](int chunk) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) patch[k] = *reinterpret_cast<const f32x4*>(xin + row_off[k >> 2] + col_off[k & 3] + chunk * 16);
-    };
-    // step = chunk*2 + half-of-frequencies; its U image (8 freq x 64 co x 16 ci, 32 KiB) is contiguous in HBM
-    auto glds_U = [&](int step, int buf) {
-        const float* src = a.w + ((long)((step >> 1) * a.grid_y + by) * 16 + (step & 1) * 8) * (64 * 16);
-        float* dst = sU + buf * W2_SU;
-#pragma unroll
-        for (int it = 0; it < 4; ++it)     // one wave-instruction = 1 KiB: LDS dest = wave-uniform base + lane*16
-            __builtin_amdgcn_global_load_lds(src + (it * 512 + tid) * 4, (lds_void*)(dst + (it * 512 + wave * 64) * 4), 16, 0, 0);
-    };
-    auto transform = [&]() {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 x0[4], x1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 da = ((ok >> (0 + j)) & 1u) ? patch[0 + j] : z;
-            f32x4 db = ((ok >> (4 + j)) & 1u) ? patch[4 + j] : z;
-            f32x4 dc = ((ok >> (8 + j)) & 1u) ? patch[8 + j] : z;
-            if (t_half == 0) { x0[j] = da - dc; x1[j] = db + dc; }
-            else             { x0[j] = db - da; x1[j] = da - dc; }
-        }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const f32x4* x = ii == 0 ? x0 : x1;
-            f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
-            float* dst = sV + (((2 * t_half + ii) * 4) * 64 + t_tile) * PST + t_q * 4;
-            *reinterpret_cast<f32x4*>(dst + 0 * 64 * PST) = v0;
-            *reinterpret_cast<f32x4*>(dst + 1 * 64 * PST) = v1;
-            *reinterpret_cast<f32x4*>(dst + 2 * 64 * PST) = v2;
-            *reinterpret_cast<f32x4*>(dst + 3 * 64 * PST) = v3;
-        }
-    };
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-
-    const float* Abase = sV + ((fh * 8) * 64 + mg * 32 + li) * PST + hh * 8;
-    const int sw = (li >> 2) & 3;                                         // chunk swizzle of row co = ng*32 + li
-    const int b_row = ((fh * 2) * 64 + ng * 32 + li) * 16;
-    const int b_c0 = ((2 * hh) ^ sw) * 4, b_c1 = ((2 * hh + 1) ^ sw) * 4;
-
-    load_P(0);
-    glds_U(0, 0);
-    transform();
-
-    const int total_steps = nchunks * 2;
-    for (int c = 0; c < nchunks; ++c) {
-        const bool has_next_chunk = (c + 1 < nchunks);
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const int step = c * 2 + st;
-            lds_dma_barrier();          // V (st == 0) and U[st] landed and visible; everyone is done with the previous step
-            if (step + 1 < total_steps) glds_U(step + 1, st ^ 1);          // in flight during this step's MFMAs
-            if (st == 0 && has_next_chunk) load_P(c + 1);
-            const float* B = sU + st * W2_SU + b_row;
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-                for (int fl = 0; fl < 2; ++fl) {
-                    const int al = (st * 2 + gg) * 2 + fl;        // local accumulator = frequency fh*8 + al
-                    f32x4 a0 = *reinterpret_cast<const f32x4*>(Abase + al * 64 * PST);
-                    f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + al * 64 * PST + 4);
-                    f32x4 b0 = *reinterpret_cast<const f32x4*>(B + (gg * 4 + fl) * 64 * 16 + b_c0);
-                    f32x4 b1 = *reinterpret_cast<const f32x4*>(B + (gg * 4 + fl) * 64 * 16 + b_c1);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[al], 0, 0, 0);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[al], 0, 0, 0);
-                }
-        }
-        if (has_next_chunk) {
-            lds_dma_barrier();          // every wave is done reading V of this chunk
-            transform();
-        }
-    }
-
-    // ---- output transform: own half in registers, partner's half through LDS (as in conv_wino8_kernel) ------------------
-    lds_dma_barrier();
-    float* ex = sV;
-    float keep[16][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float s0[2], s1[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r], m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
-            s0[i] = m0 + m1 + m2;
-            s1[i] = m1 - m2 - m3;
-        }
-        float send0, send1;
-        if (fh == 0) {
-            keep[r][0] = s0[0] + s0[1]; keep[r][1] = s1[0] + s1[1];
-            send0 = s0[1]; send1 = s1[1];
-        } else {
-            keep[r][0] = -s0[0] - s0[1]; keep[r][1] = -s1[0] - s1[1];
-            send0 = s0[0]; send1 = s1[0];
-        }
-        ex[((wave * 16 + r) * 2 + 0) * 64 + lane] = send0;
-        ex[((wave * 16 + r) * 2 + 1) * 64 + lane] = send1;
-    }
-    lds_dma_barrier();
-    const int partner = wave ^ 4;
-    const int co = co0 + ng * 32 + li;
-    const bool cvalid = co < a.Cout;
-    const float sc = cvalid ? P.scale[co] : 0.f;
-    const float sh = cvalid ? P.shift[co] : 0.f;
-    const bool do_relu = co < a.relu_upto;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int t = mg * 32 + row;
-        const int oh = oh0 + 2 * (t >> 3) + fh, ow = ow0 + 2 * (t & 7);
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            float yv = keep[r][dx] + ex[((partner * 16 + r) * 2 + dx) * 64 + lane];
-            if (cvalid && oh < H && ow + dx < W) {
-                float v = yv * sc + sh;
-                if (do_relu) v = fmaxf(v, 0.f);
-                P.y[(((long)n * H + oh) * W + ow + dx) * a.y_cs + a.y_co + co] = v;
-            }
-        }
-    }
 }
 
 // Fourth form, built for residency: a 4-wave workgroup covers 8x16 output pixels (32 tiles) x 64 couts, the two frequency
@@ -1187,11 +818,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
 static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
         if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1208,12 +835,8 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     a.grid_y = cdiv(a.Cout, 64);
     if (waves8 == 3)
         hipLaunchKernelGGL(conv_wino4s_kernel, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a);
-    else if (waves8 == 2)
-        hipLaunchKernelGGL(conv_wino8b_kernel, dim3(blocks * a.grid_y), dim3(512), W2_LDS_BYTES, st, a);
-    else if (waves8)
-        hipLaunchKernelGGL(conv_wino8_kernel, dim3(blocks * a.grid_y), dim3(512), W_LDS_BYTES, st, a);
     else
-        hipLaunchKernelGGL(conv_wino_kernel, dim3(blocks * a.grid_y), dim3(256), W_LDS_BYTES, st, a);
+        hipLaunchKernelGGL(conv_wino8_kernel, dim3(blocks * a.grid_y), dim3(512), W_LDS_BYTES, st, a);
     return check_launch("conv_wino");
 }
 
@@ -1376,11 +999,10 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const int cout32 = (d->Cout + 31) / 32;
     const int taps = d->ksize * d->ksize;
     hipStream_t st = (hipStream_t)stream;
-    if (d->tune_wm >= 3 && d->tune_wm <= 6) {          // Winograd F(2x2,3x3) (3 = 4 waves, 4 = 8 waves, 5 = 8 waves with register-staged patches, 6 = 4 waves x 2 workgroups per CU): 3x3 stride 1, no residual / input ReLU
+    if (d->tune_wm == 4 || d->tune_wm == 6) {          // Winograd F(2x2,3x3) (4 = 8 waves / 1 workgroup per CU, 6 = 4 waves x 2 workgroups per CU): 3x3 stride 1, no residual / input ReLU
         if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino || (d->in_scale && d->tune_wm != 6))
             return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
         a.w = d->w_wino;
-        if (d->tune_wm == 5 && (long)d->H * d->W * d->x_cs >= (1L << 31)) return fail(CMK_EINVAL, "conv: image too large for 32-bit patch offsets%s", "");
         return launch_wino(a, d->tune_wm - 3, st);
     }
     Variant v;

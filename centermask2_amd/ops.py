@@ -208,7 +208,7 @@ def _tune(descs, n, key) -> None:
     best, best_ms = (0, 0, 0), float("inf")
     cands = [(wm, sc, wn) for wn in range(1, 8) for wm in (1, 2) for sc in (16, 32)]
     if ALLOW_WINOGRAD:
-        cands += [(3, 16, 2), (4, 16, 2), (5, 16, 2), (6, 16, 2)]         # fused Winograd F(2x2,3x3), 4- and 8-wave forms (3x3 stride 1 without residual only)
+        cands += [(4, 16, 2), (6, 16, 2)]         # fused Winograd F(2x2,3x3): 8-wave / 1 WG per CU and 4-wave / 2 WG per CU forms
     for wm, sc, wn in cands:
         for _once in (0,):
             for _once2 in (0,):
@@ -519,8 +519,8 @@ def _kernel_name(taps, stride, tv) -> str:
     """The template instantiation rocprofv3 will report: conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>."""
     if not tv or tv == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
-    if tv[0] in (3, 4, 5, 6):
-        return "cmk::conv_wino{}_kernel".format({3: "", 4: "8", 5: "8b", 6: "4s"}[tv[0]])
+    if tv[0] in (4, 6):
+        return "cmk::conv_wino{}_kernel".format({4: "8", 6: "4s"}[tv[0]])
     wm, sc, wn = tv
     return "conv_igemm_kernel<{}, {}, {}, {}, {}>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
 

@@ -49,7 +49,8 @@ typedef struct {
      * tune_wn in 1..7 (32*tune_wn output channels per workgroup; must divide the padded Cout).  Results are bitwise
      * identical across variants (the K order per output does not depend on the tile). */
     int tune_wm; int tune_sc; int tune_wn;
-    /* tune_wm == 3 (4 waves) or 4 (8 waves) selects the fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual): same fp32 arithmetic on the
+    /* tune_wm == 6 (4 waves, two workgroups per CU; the default for 3x3 stride 1) or 4 (8 waves, one workgroup per CU) selects the
+     * fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual): same fp32 arithmetic on the
      * matrix pipe with 2.25x fewer multiplies; results differ from the direct kernel by fp32 rounding only.  It needs the
      * weights pre-transformed to U = G g G^T, packed [Cin/16][ceil(Cout/64)][16 freq in step order][64][16] (cmk_wino_packed_floats);
      * step g streams the frequencies {2g, 2g+1, 8+2g, 9+2g} of the row-major 4x4 frequency grid; within a 64-byte row

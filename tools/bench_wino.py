@@ -28,12 +28,9 @@ for name, h, w, cin, cout in SHAPES:
             for sc in (16, 32):
                 d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = wm, sc, wn
                 if lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) == 0: best = min(best, timeit(d[0]))
-    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 3, 16, 2
-    tw = timeit(d[0])
-    d[0].tune_wm = 4
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 4, 16, 2
     tw8 = timeit(d[0])
-    d[0].tune_wm = 5
-    tw8b = timeit(d[0])
+    tw = tw8b = float("nan")          # the 4-wave/16-accumulator and register-patch forms were removed (slower on every shape)
     d[0].tune_wm = 6
     tw4s = timeit(d[0])
     fl = 2.0 * n * h * w * cin * cout * 9
