@@ -58,6 +58,7 @@ struct ConvArgs {
     int x_cs, x_co, y_cs, y_co, res_cs, res_co, res_mode, Hr, Wr;
     int relu_upto, in_relu;
     int cout_pad;
+    int total_tiles;   // spatial tiles of all problems (XCD-aware kernels pad the grid to a multiple of 8 tiles)
     int grid_y;   // N tiles; the N-tile index is the FASTEST block coordinate so the workgroups sharing an input tile run together (L2 reuse)
 };
 
@@ -96,7 +97,10 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
     const int li = lane & 31;
 
     // ---- which problem (FPN level) and which tile ------------------------------------------------------------
-    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
+    // XCD-aware order (see conv_wino4s_kernel): the grid_y workgroups of one input tile go to one XCD, back to back
+    const int xq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int bx = (xq / a.grid_y) * 8 + xcd, by = xq % a.grid_y;
+    if (bx >= a.total_tiles) return;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAXP; ++i)
@@ -580,7 +584,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     const int hh = lane >> 5, li = lane & 31;
     const int fh = wave >> 1, ng = wave & 1;
 
-    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the grid_y workgroups that
+    // share an input tile are given to the SAME XCD, back to back: the tile's halo is fetched into one L2 once.
+    // (b % 8 only says which workgroups share an XCD; nothing here depends on it for correctness.)
+    const int xq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int bx = (xq / a.grid_y) * 8 + xcd, by = xq % a.grid_y;
+    if (bx >= a.total_tiles) return;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAXP; ++i)
@@ -833,8 +842,9 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
         blocks += p.N * p.tiles_h * p.tiles_w;
     }
     a.grid_y = cdiv(a.Cout, 64);
+    a.total_tiles = blocks;
     if (waves8 == 3)
-        hipLaunchKernelGGL(conv_wino4s_kernel, dim3(blocks * a.grid_y), dim3(256), S_LDS_BYTES, st, a);
+        hipLaunchKernelGGL(conv_wino4s_kernel, dim3(((blocks + 7) / 8) * 8 * a.grid_y), dim3(256), S_LDS_BYTES, st, a);
     else
         hipLaunchKernelGGL(conv_wino8_kernel, dim3(blocks * a.grid_y), dim3(512), W_LDS_BYTES, st, a);
     return check_launch("conv_wino");
@@ -870,7 +880,8 @@ static int launch(ConvArgs& a, int grid_y, hipStream_t st) {
         }
     }
     a.grid_y = grid_y;
-    hipLaunchKernelGGL(kern, dim3(blocks * grid_y), dim3(256), G::LDS_BYTES, st, a);
+    a.total_tiles = blocks;
+    hipLaunchKernelGGL(kern, dim3(((blocks + 7) / 8) * 8 * grid_y), dim3(256), G::LDS_BYTES, st, a);
     return check_launch("conv_igemm");
 }
 
