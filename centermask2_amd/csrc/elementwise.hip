@@ -6,59 +6,70 @@
 namespace cmk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------------------
 // stem_1 (vovnet.py:409): conv3x3 s2 p1 on (N,3,H,W) NCHW -> (N,Ho,Wo,Cout) NHWC, y = relu(acc*scale + shift).
 // 4 threads per output pixel, 16 output channels each (Cout = 64); 27 taps broadcast from LDS.
 // ---------------------------------------------------------------------------------------------------------------
+template <int NB>   // NB = Cout / 32
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       float* __restrict__ y, int N, int H, int W, int Ho, int Wo, int Cout) {
-    extern __shared__ __attribute__((aligned(16))) float sw[];  // [27][Cout] + scale[Cout] + shift[Cout]
-    for (int i = threadIdx.x; i < 27 * Cout; i += 256) sw[i] = w[i];
-    for (int i = threadIdx.x; i < Cout; i += 256) { sw[27 * Cout + i] = scale[i]; sw[28 * Cout + i] = shift[i]; }
-    __syncthreads();
-    const int groups = Cout >> 4;             // 16-channel groups per pixel
-    const int ppb = 256 / groups;             // pixels per block
-    const int g = threadIdx.x % groups;
-    const long pix = (long)blockIdx.x * ppb + threadIdx.x / groups;
+                                                       float* __restrict__ y, int N, int H, int W, int Ho, int Wo, long tiles) {
+    // GEMM on the matrix pipe: M = output pixels (32 per wave tile), K = 27 taps padded to 28, N = Cout.
+    // A[pixel][k] is gathered straight from the NCHW image (lane = pixel, lane>>5 = k parity), the 14 x NB weight
+    // operands B[k][cout] stay in registers for the whole kernel, the accumulators come out with cout on the lane so
+    // every store instruction writes two full 128-byte NHWC runs.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, hh = lane >> 5;
+    constexpr int Cout = NB * 32;
+    float b[14][NB], sc[NB], sh[NB];
+    int dlt[14], khs[14], kws[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int k = 2 * s + hh;                 // tap index (kh*3+kw)*3+ci, 27 = padding
+        const int ci = k % 3, t = k / 3, kw = t % 3, kh = t / 3;
+        khs[s] = kh - 1; kws[s] = kw - 1;
+        dlt[s] = (ci * H + kh - 1) * W + kw - 1;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[s][nb] = k < 27 ? w[k * Cout + nb * 32 + li] : 0.f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { sc[nb] = scale[nb * 32 + li]; sh[nb] = shift[nb * 32 + li]; }
     const long total = (long)N * Ho * Wo;
-    if (pix >= total) return;
-    const int ow = (int)(pix % Wo);
-    const int oh = (int)((pix / Wo) % Ho);
-    const int n = (int)(pix / ((long)Wo * Ho));
-    float acc[16];
+    const long hw = (long)Ho * Wo;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+        const long pix = tile * 32 + li;
+        const bool pv = pix < total;
+        const int n = (int)(pix / hw);
+        const int rem = (int)(pix - (long)n * hw);
+        const int oh = rem / Wo, ow = rem - oh * Wo;
+        const int ih0 = oh * 2, iw0 = ow * 2;
+        const float* xb = x + ((long)n * 3 * H + ih0) * W + iw0;
+        float av[14];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    const float* xn = x + (long)n * 3 * H * W;
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
-                float v = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xn[((long)ci * H + ih) * W + iw] : 0.f;
-                const f32x4* wr = reinterpret_cast<const f32x4*>(sw + ((kh * 3 + kw) * 3 + ci) * Cout + g * 16);  // tap-major [kh][kw][ci][co]
-#pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) {      // 4 x ds_read_b128 per tap instead of 16 x ds_read_b32
-                    const f32x4 w4 = wr[j4];
-                    acc[j4 * 4 + 0] = fmaf(v, w4.x, acc[j4 * 4 + 0]);
-                    acc[j4 * 4 + 1] = fmaf(v, w4.y, acc[j4 * 4 + 1]);
-                    acc[j4 * 4 + 2] = fmaf(v, w4.z, acc[j4 * 4 + 2]);
-                    acc[j4 * 4 + 3] = fmaf(v, w4.w, acc[j4 * 4 + 3]);
-                }
-            }
-    float* yo = y + pix * Cout + g * 16;
-#pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int c = g * 16 + j4 * 4 + j;
-            o[j] = fmaxf(acc[j4 * 4 + j] * sw[27 * Cout + c] + sw[28 * Cout + c], 0.f);
+        for (int s = 0; s < 14; ++s) {
+            const int ih = ih0 + khs[s], iw = iw0 + kws[s];
+            const bool ok = pv && (2 * s + hh < 27) && ih >= 0 && ih < H && iw >= 0 && iw < W;
+            av[s] = ok ? xb[dlt[s]] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(yo + j4 * 4) = o;
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 14; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b[s][nb], acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long op = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (op < total) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) y[op * Cout + nb * 32 + li] = fmaxf(acc[nb][r] * sc[nb] + sh[nb], 0.f);
+            }
+        }
     }
 }
 
@@ -129,21 +140,37 @@ __global__ __launch_bounds__(256) void ese_partial_kernel(const float* __restric
 __global__ __launch_bounds__(256) void ese_fc_kernel(const float* __restrict__ ws, const float* __restrict__ fc_w,
                                                     const float* __restrict__ fc_b, float* __restrict__ gate, int HW, int C,
                                                     int chunks) {
-    extern __shared__ float mean[];  // [C]
+    // 16 outputs per workgroup.  Stage 1 reduces the per-chunk partial sums to the channel means: the chunk range is split over
+    // `parts` thread groups (16 B per thread per chunk, independent loads), folded through LDS.  Stage 2: one wave per output.
+    extern __shared__ float sm[];  // [parts][C] partials, then mean in row 0
     const int n = blockIdx.y;
+    const int G = C >> 2;
+    const int parts = G >= 256 ? 1 : 256 / G;
+    const float* wsn = ws + (long)n * chunks * C;
+    for (int gi = threadIdx.x; gi < G * parts; gi += 256) {
+        const int g = gi % G, part = gi / G;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int k = part; k < chunks; k += parts) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(wsn + (long)k * C + g * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<f32x4*>(sm + part * C + g * 4) = s;
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = 0.f;
-        for (int k = 0; k < chunks; ++k) s += ws[((long)n * chunks + k) * C + c];
-        mean[c] = s / (float)HW;
+        for (int part = 0; part < parts; ++part) s += sm[part * C + c];
+        sm[c] = s / (float)HW;   // row 0 is only read by its own thread above
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = blockIdx.x * 64 + wave; o < min(C, (int)(blockIdx.x + 1) * 64); o += 4) {
+    for (int o = blockIdx.x * 16 + wave; o < min(C, (int)(blockIdx.x + 1) * 16); o += 4) {
         const float* wr = fc_w + (long)o * C;
         float s = 0.f;
         for (int c = lane * 4; c < C; c += 256) {
             f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-            s += wv.x * mean[c] + wv.y * mean[c + 1] + wv.z * mean[c + 2] + wv.w * mean[c + 3];
+            s += wv.x * sm[c] + wv.y * sm[c + 1] + wv.z * sm[c + 2] + wv.w * sm[c + 3];
         }
         s = wave_sum(s);
         if (lane == 0) {
@@ -356,13 +383,18 @@ using namespace cmk;
 extern "C" int cmk_stem_conv_nchw3(const float* x, const float* w, const float* scale, const float* shift, float* y, int N, int H,
                                    int W, int Cout, void* stream) {
     if (!x || !w || !scale || !shift || !y) return fail(CMK_EINVAL, "stem: null pointer%s", "");
-    if (Cout <= 0 || (Cout & 15) || 256 % (Cout >> 4)) return fail(CMK_EINVAL, "stem: Cout (%s%ld) must be 16*2^k <= 4096", "", Cout);
+    if (Cout != 32 && Cout != 64 && Cout != 128) return fail(CMK_EINVAL, "stem: Cout (%s%ld) must be 32, 64 or 128", "", (long)Cout);
     int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     long total = (long)N * Ho * Wo;
-    int ppb = 256 / (Cout >> 4);
-    size_t lds = (size_t)29 * Cout * sizeof(float);
-    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), lds, (hipStream_t)stream, x, w, scale,
-                       shift, y, N, H, W, Ho, Wo, Cout);
+    if ((long)3 * H * W >= (1L << 31)) return fail(CMK_EINVAL, "stem: image too large%s", "");
+    long tiles = (total + 31) / 32;
+    unsigned grid = (unsigned)std::min<long>((tiles + 3) / 4, 256 * 16);
+    if (Cout == 32)
+        hipLaunchKernelGGL(stem_conv_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, N, H, W, Ho, Wo, tiles);
+    else if (Cout == 64)
+        hipLaunchKernelGGL(stem_conv_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, N, H, W, Ho, Wo, tiles);
+    else
+        hipLaunchKernelGGL(stem_conv_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, N, H, W, Ho, Wo, tiles);
     return check_launch("stem_conv");
 }
 
@@ -390,7 +422,7 @@ extern "C" int cmk_ese_gate(const float* x, int x_cs, int x_co, const float* fc_
     hipLaunchKernelGGL(ese_partial_kernel, dim3(ws_chunks, N), dim3(256), lds1, (hipStream_t)stream, x, x_cs, x_co, ws, HW, C, ws_chunks);
     int rc = check_launch("ese_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(ese_fc_kernel, dim3(cdiv(C, 64), N), dim3(256), (size_t)C * sizeof(float), (hipStream_t)stream, ws, fc_w, fc_b,
+    hipLaunchKernelGGL(ese_fc_kernel, dim3(cdiv(C, 16), N), dim3(256), lds1, (hipStream_t)stream, ws, fc_w, fc_b,
                        gate, HW, C, ws_chunks);
     return check_launch("ese_fc");
 }

@@ -325,12 +325,17 @@ def maxpool3x3s2_ceil(x: View, y: Optional[View] = None, gate: Optional[torch.Te
     return y
 
 
+def _ese_chunks(hw: int, c: int) -> int:
+    """Pixel chunks per image for the eSE average pool: ~32K elements per workgroup so even the 25x40 stage fills the chip."""
+    return max(1, min(256, (hw * c) // 32768))
+
+
 def ese_gate(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.Tensor:
     """gate (N,C) = hsigmoid(fc(mean_HW(x)))   (vovnet.py:255-259)."""
     lib = _lib.load()
     n, h, w = x.nhw
     hw, c = h * w, x.c
-    chunks = max(1, min(256, hw // 256))
+    chunks = _ese_chunks(hw, c)
     ws = torch.empty((n, chunks, c), dtype=torch.float32, device=x.t.device)
     gate = torch.empty((n, c), dtype=torch.float32, device=x.t.device)
     check(lib.cmk_ese_gate(x.t.data_ptr(), x.cs, x.co, fc_w.data_ptr(), fc_b.data_ptr(), gate.data_ptr(), ws.data_ptr(), chunks,
@@ -343,7 +348,7 @@ def ese(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor, y: View, identity: Opti
     lib = _lib.load()
     n, h, w = x.nhw
     hw, c = h * w, x.c
-    chunks = max(1, min(256, hw // 256))
+    chunks = _ese_chunks(hw, c)
     ws = torch.empty((n, chunks, c), dtype=torch.float32, device=x.t.device)
     gate = torch.empty((n, c), dtype=torch.float32, device=x.t.device)
     check(lib.cmk_ese_gate(x.t.data_ptr(), x.cs, x.co, fc_w.data_ptr(), fc_b.data_ptr(), gate.data_ptr(), ws.data_ptr(), chunks,
