@@ -42,6 +42,7 @@ SIGNATURES = {
     "cmk_conv_packed_floats": (c_int64, [c_int, c_int, c_int]),
     "cmk_conv_cout_pad": (c_int, [c_int]),
     "cmk_wino_packed_floats": (c_int64, [c_int, c_int]),
+    "cmk_dwconv3x3_nhwc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_stem_conv_nchw3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_maxpool3x3s2_ceil_nhwc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cmk_ese_gate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -73,6 +73,59 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     }
 }
 
+// depth-wise 3x3 (vovnet.py:110-119 'dw_conv3x3': groups = channels, pad 1, no bias, no activation; the point-wise 1x1 +
+// FrozenBN + ReLU that follows is an ordinary conv launch).  HBM-bound: one thread = 4 channels x T adjacent output columns,
+// so the 3 x (T*S+2) input quads are each loaded once per thread and the 9 weight quads live in registers.
+template <int S, int T>
+__global__ __launch_bounds__(256) void dwconv3_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ w,
+                                                     float* __restrict__ y, int y_cs, int y_co, int N, int H, int W, int Ho, int Wo,
+                                                     int C4) {
+    const int WT = (Wo + T - 1) / T;
+    const long total = (long)N * Ho * WT * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        long r = i / C4;
+        const int wt = (int)(r % WT);
+        r /= WT;
+        const int oh = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        f32x4 wq[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wq[t] = *reinterpret_cast<const f32x4*>(w + (long)t * C4 * 4 + c4 * 4);
+        f32x4 acc[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int iw0 = wt * T * S - 1;
+        constexpr int COLS = (T - 1) * S + 3;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * S - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+            const float* row = x + ((long)n * H + ih) * W * x_cs + x_co + c4 * 4;
+#pragma unroll
+            for (int cc = 0; cc < COLS; ++cc) {
+                const int iw = iw0 + cc;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (iw >= 0 && iw < W) v = *reinterpret_cast<const f32x4*>(row + (long)iw * x_cs);
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const int kw = cc - j * S;       // compile-time after unrolling
+                    if (kw >= 0 && kw < 3) {
+                        const f32x4 wv = wq[kh * 3 + kw];
+                        acc[j].x = fmaf(v.x, wv.x, acc[j].x); acc[j].y = fmaf(v.y, wv.y, acc[j].y);
+                        acc[j].z = fmaf(v.z, wv.z, acc[j].z); acc[j].w = fmaf(v.w, wv.w, acc[j].w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int ow = wt * T + j;
+            if (ow < Wo) *reinterpret_cast<f32x4*>(y + (((long)n * Ho + oh) * Wo + ow) * y_cs + y_co + c4 * 4) = acc[j];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // MaxPool2d(3, 2, ceil_mode=True), no padding (vovnet.py:349-350).  One lane = one output pixel x 4 channels.
 // ---------------------------------------------------------------------------------------------------------------
@@ -396,6 +449,25 @@ extern "C" int cmk_stem_conv_nchw3(const float* x, const float* w, const float* 
     else
         hipLaunchKernelGGL(stem_conv_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, N, H, W, Ho, Wo, tiles);
     return check_launch("stem_conv");
+}
+
+extern "C" int cmk_dwconv3x3_nhwc(const float* x, int x_cs, int x_co, const float* w, float* y, int y_cs, int y_co, int N, int H, int W,
+                                  int C, int stride, void* stream) {
+    if (!x || !w || !y) return fail(CMK_EINVAL, "dwconv: null pointer%s", "");
+    if ((C & 3) || (x_cs & 3) || (x_co & 3) || (y_cs & 3) || (y_co & 3) || C < 4) return fail(CMK_EINVAL, "dwconv: channels must be multiples of 4%s", "");
+    if (stride != 1 && stride != 2) return fail(CMK_EINVAL, "dwconv: stride must be 1 or 2%s", "");
+    if (N < 1 || H < 1 || W < 1) return fail(CMK_EINVAL, "dwconv: empty input%s", "");
+    int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    if (stride == 1) {
+        long total = (long)N * Ho * ((Wo + 3) / 4) * (C >> 2);
+        hipLaunchKernelGGL((dwconv3_kernel<1, 4>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, w, y, y_cs,
+                           y_co, N, H, W, Ho, Wo, C >> 2);
+    } else {
+        long total = (long)N * Ho * ((Wo + 1) / 2) * (C >> 2);
+        hipLaunchKernelGGL((dwconv3_kernel<2, 2>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, w, y, y_cs,
+                           y_co, N, H, W, Ho, Wo, C >> 2);
+    }
+    return check_launch("dwconv3");
 }
 
 extern "C" int cmk_maxpool3x3s2_ceil_nhwc(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int H, int W, int C,

@@ -24,8 +24,12 @@ from .fpn import FPN, LastLevelP6, LastLevelP6P7
 
 __all__ = ["VoVNet", "build_vovnet_backbone", "build_fcos_vovnet_fpn_backbone", "_STAGE_SPECS"]
 
-# vovnet.py:60-108; the depthwise ("dw") variants need a depth-wise kernel and are not built yet
+# vovnet.py:30-108
 _STAGE_SPECS = {
+    "V-19-slim-dw-eSE": dict(stem=[64, 64, 64], stage_conv_ch=[64, 80, 96, 112], stage_out_ch=[112, 256, 384, 512],
+                             layer_per_block=3, block_per_stage=[1, 1, 1, 1], eSE=True, dw=True),
+    "V-19-dw-eSE": dict(stem=[64, 64, 64], stage_conv_ch=[128, 160, 192, 224], stage_out_ch=[256, 512, 768, 1024],
+                        layer_per_block=3, block_per_stage=[1, 1, 1, 1], eSE=True, dw=True),
     "V-19-slim-eSE": dict(stem=[64, 64, 128], stage_conv_ch=[64, 80, 96, 112], stage_out_ch=[112, 256, 384, 512],
                           layer_per_block=3, block_per_stage=[1, 1, 1, 1], eSE=True, dw=False),
     "V-19-eSE": dict(stem=[64, 64, 128], stage_conv_ch=[128, 160, 192, 224], stage_out_ch=[256, 512, 768, 1024],
@@ -46,6 +50,28 @@ def _conv_bn(in_ch, out_ch, module_name, postfix, k, stride=1):
     return [("{}_{}/conv".format(module_name, postfix), conv), ("{}_{}/norm".format(module_name, postfix), FrozenBatchNorm2d(out_ch))]
 
 
+def _dw_pw_bn(ch, module_name, postfix, stride=1):
+    """Parameter holders of dw_conv3x3 (vovnet.py:110-130): '/dw_conv3x3' (depth-wise, carries the stride), '/pw_conv1x1', '/pw_norm'."""
+    dw = nn.Conv2d(ch, ch, kernel_size=3, stride=stride, padding=1, groups=ch, bias=False)
+    pw = nn.Conv2d(ch, ch, kernel_size=1, bias=False)
+    nn.init.kaiming_normal_(pw.weight)
+    base = "{}_{}".format(module_name, postfix)
+    return [(base + "/dw_conv3x3", dw), (base + "/pw_conv1x1", pw), (base + "/pw_norm", FrozenBatchNorm2d(ch))]
+
+
+def _fold_dw(seq: nn.Module, name: str, dev, stride=1):
+    """-> (tap-major dw weight on the device, PackedConv of the point-wise 1x1 with the FrozenBN folded in, stride)."""
+    dw, pw, norm = getattr(seq, name + "/dw_conv3x3"), getattr(seq, name + "/pw_conv1x1"), getattr(seq, name + "/pw_norm")
+    scale, shift = ops.fold_frozen_bn(norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps)
+    return ops.pack_dw_weight(dw.weight).to(dev), ops.PackedConv(pw.weight, scale, shift, dev), stride
+
+
+def _dw_layer(src: View, packed, dst: View) -> None:
+    """dw 3x3 into a scratch tensor, then the 1x1 + BN + ReLU into the destination slice."""
+    w9c, pw, stride = packed
+    ops.conv2d(ops.dwconv3x3(src, w9c, stride=stride), pw, dst, relu=True)
+
+
 def _fold(seq: nn.Module, name: str):
     conv, norm = getattr(seq, name + "/conv"), getattr(seq, name + "/norm")
     scale, shift = ops.fold_frozen_bn(norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps)
@@ -59,14 +85,22 @@ class eSEModule(nn.Module):
 
 
 class _OSA_module(nn.Module):
-    def __init__(self, in_ch, stage_ch, concat_ch, layer_per_block, module_name, identity=False):
+    def __init__(self, in_ch, stage_ch, concat_ch, layer_per_block, module_name, identity=False, depthwise=False):
         super().__init__()
         self.identity = identity
+        self.depthwise = depthwise
+        self.isReduced = False
         self.in_ch, self.stage_ch, self.concat_ch, self.module_name = in_ch, stage_ch, concat_ch, module_name
         self.layers = nn.ModuleList()
         c = in_ch
+        if depthwise and in_ch != stage_ch:         # vovnet.py:284-288
+            self.isReduced = True
+            self.conv_reduction = nn.Sequential(OrderedDict(_conv_bn(in_ch, stage_ch, module_name + "_reduction", "0", 1)))
         for i in range(layer_per_block):
-            seq = nn.Sequential(OrderedDict(_conv_bn(c, stage_ch, module_name, i, 3)))
+            if depthwise:
+                seq = nn.Sequential(OrderedDict(_dw_pw_bn(stage_ch, module_name, i)))
+            else:
+                seq = nn.Sequential(OrderedDict(_conv_bn(c, stage_ch, module_name, i, 3)))
             self.layers.append(seq)
             c = stage_ch
         self.cat_ch = in_ch + layer_per_block * stage_ch
@@ -75,14 +109,14 @@ class _OSA_module(nn.Module):
 
 
 class _OSA_stage(nn.Sequential):
-    def __init__(self, in_ch, stage_ch, concat_ch, block_per_stage, layer_per_block, stage_num):
+    def __init__(self, in_ch, stage_ch, concat_ch, block_per_stage, layer_per_block, stage_num, depthwise=False):
         super().__init__()
         self.stage_num = stage_num
         name = "OSA{}_1".format(stage_num)
-        self.add_module(name, _OSA_module(in_ch, stage_ch, concat_ch, layer_per_block, name))
+        self.add_module(name, _OSA_module(in_ch, stage_ch, concat_ch, layer_per_block, name, depthwise=depthwise))
         for i in range(block_per_stage - 1):
             name = "OSA{}_{}".format(stage_num, i + 2)
-            self.add_module(name, _OSA_module(concat_ch, stage_ch, concat_ch, layer_per_block, name, identity=True))
+            self.add_module(name, _OSA_module(concat_ch, stage_ch, concat_ch, layer_per_block, name, identity=True, depthwise=depthwise))
 
     def blocks(self):
         return [m for m in self.children() if isinstance(m, _OSA_module)]
@@ -93,7 +127,7 @@ class VoVNet(Backbone):
         super().__init__()
         body = cfg.MODEL.VOVNET.CONV_BODY
         if body not in _STAGE_SPECS:
-            raise NotImplementedError("VoVNet body {} (depth-wise variants are not built)".format(body))
+            raise NotImplementedError("unknown VoVNet body {}".format(body))
         if cfg.MODEL.VOVNET.NORM != "FrozenBN":
             raise NotImplementedError("MODEL.VOVNET.NORM={} (inference path folds FrozenBN)".format(cfg.MODEL.VOVNET.NORM))
         if any(cfg.MODEL.VOVNET.STAGE_WITH_DCN):
@@ -101,10 +135,16 @@ class VoVNet(Backbone):
         assert input_ch == 3, "stem kernel reads a 3-channel image"
         spec = _STAGE_SPECS[body]
         stem_ch = spec["stem"]
+        self.depthwise = spec["dw"]
         self._out_features = list(out_features)
         stem = _conv_bn(input_ch, stem_ch[0], "stem", "1", 3, 2)
-        stem += _conv_bn(stem_ch[0], stem_ch[1], "stem", "2", 3, 1)
-        stem += _conv_bn(stem_ch[1], stem_ch[2], "stem", "3", 3, 2)
+        if self.depthwise:                           # vovnet.py:408-411
+            assert stem_ch[0] == stem_ch[1] == stem_ch[2], "dw_conv3x3 keeps the channel count"
+            stem += _dw_pw_bn(stem_ch[1], "stem", "2", 1)
+            stem += _dw_pw_bn(stem_ch[2], "stem", "3", 2)
+        else:
+            stem += _conv_bn(stem_ch[0], stem_ch[1], "stem", "2", 3, 1)
+            stem += _conv_bn(stem_ch[1], stem_ch[2], "stem", "3", 3, 2)
         self.add_module("stem", nn.Sequential(OrderedDict(stem)))
         stride = 4
         self._out_feature_strides = {"stem": stride, "stage2": stride}
@@ -115,7 +155,7 @@ class VoVNet(Backbone):
             name = "stage%d" % (i + 2)
             self.stage_names.append(name)
             self.add_module(name, _OSA_stage(in_ch_list[i], spec["stage_conv_ch"][i], spec["stage_out_ch"][i],
-                                             spec["block_per_stage"][i], spec["layer_per_block"], i + 2))
+                                             spec["block_per_stage"][i], spec["layer_per_block"], i + 2, depthwise=self.depthwise))
             self._out_feature_channels[name] = spec["stage_out_ch"][i]
             if i != 0:
                 stride *= 2
@@ -127,12 +167,21 @@ class VoVNet(Backbone):
         conv, sc, sh = _fold(self.stem, "stem_1")
         P["stem_1"] = (conv.weight.detach().float().cpu().permute(2, 3, 1, 0).reshape(27, -1).contiguous().to(dev), sc.to(dev), sh.to(dev))
         for nm, stride in (("stem_2", 1), ("stem_3", 2)):
+            if self.depthwise:
+                P[nm] = _fold_dw(self.stem, nm, dev, stride)
+                continue
             conv, sc, sh = _fold(self.stem, nm)
             P[nm] = ops.PackedConv(conv.weight, sc, sh, dev, stride=stride)
         for sname in self.stage_names:
             for blk in getattr(self, sname).blocks():
                 mn = blk.module_name
+                if blk.isReduced:
+                    conv, sc, sh = _fold(blk.conv_reduction, mn + "_reduction_0")
+                    P[mn + "_reduction"] = ops.PackedConv(conv.weight, sc, sh, dev)
                 for i, seq in enumerate(blk.layers):
+                    if blk.depthwise:
+                        P["{}_{}".format(mn, i)] = _fold_dw(seq, "{}_{}".format(mn, i), dev)
+                        continue
                     conv, sc, sh = _fold(seq, "{}_{}".format(mn, i))
                     P["{}_{}".format(mn, i)] = ops.PackedConv(conv.weight, sc, sh, dev)
                 conv, sc, sh = _fold(blk.concat, mn + "_concat")
@@ -152,7 +201,11 @@ class VoVNet(Backbone):
         outputs = {}
         w27, sc, sh = P["stem_1"]
         s1 = ops.stem_conv(x.float(), w27, sc, sh)
-        s2 = ops.conv_out(s1, P["stem_2"], relu=True)
+        if self.depthwise:
+            s2 = View(torch.empty_like(s1.t))
+            _dw_layer(s1, P["stem_2"], s2)
+        else:
+            s2 = ops.conv_out(s1, P["stem_2"], relu=True)
         n = x.shape[0]
         prev = None        # dense output View of the previous stage
         prev_gate = None   # eSE gate still to be applied to `prev` (folded into the next max pool)
@@ -166,20 +219,26 @@ class VoVNet(Backbone):
             inp = View(cat, 0, blocks[0].in_ch)
             if sname == "stage2":
                 if "stem" in self._out_features:
-                    stem_out = ops.conv_out(s2, P["stem_3"], relu=True)
+                    stem_out = View(torch.empty((n, h, w, blocks[0].in_ch), dtype=torch.float32, device=dev))
+                    self._stem3(s2, P["stem_3"], stem_out)
                     outputs["stem"] = stem_out
                     inp.t[..., :blocks[0].in_ch].copy_(stem_out.t)
                 else:
-                    ops.conv2d(s2, P["stem_3"], inp, relu=True)
+                    self._stem3(s2, P["stem_3"], inp)
             else:
                 ops.maxpool3x3s2_ceil(prev, inp, gate=prev_gate)     # vovnet.py:349-350 (+ the pending eSE scale, see below)
                 prev_gate = None
             for b, blk in enumerate(blocks):
                 mn = blk.module_name
                 src, off = inp, blk.in_ch
+                if blk.isReduced:                                              # vovnet.py:317-318
+                    src = ops.conv_out(inp, P[mn + "_reduction"], relu=True)
                 for i in range(len(blk.layers)):
                     dst = View(cat, off, blk.stage_ch)
-                    ops.conv2d(src, P["{}_{}".format(mn, i)], dst, relu=True)
+                    if blk.depthwise:
+                        _dw_layer(src, P["{}_{}".format(mn, i)], dst)
+                    else:
+                        ops.conv2d(src, P["{}_{}".format(mn, i)], dst, relu=True)
                     src, off = dst, off + blk.stage_ch
                 xt = ops.conv_out(View(cat), P[mn + "_concat"], relu=True)     # 1x1 over the un-materialised concat
                 if b + 1 < len(blocks):
@@ -202,6 +261,12 @@ class VoVNet(Backbone):
             if sname in self._out_features:
                 outputs[sname] = out
         return outputs
+
+    def _stem3(self, s2: View, packed, dst: View) -> None:
+        if self.depthwise:
+            _dw_layer(s2, packed, dst)
+        else:
+            ops.conv2d(s2, packed, dst, relu=True)
 
     def forward(self, x):
         return {k: v.nchw() for k, v in self.forward_views(x).items()}

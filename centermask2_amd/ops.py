@@ -307,6 +307,26 @@ def stem_conv(x_nchw: torch.Tensor, w27: torch.Tensor, scale: torch.Tensor, shif
     return View(y)
 
 
+def pack_dw_weight(weight: torch.Tensor) -> torch.Tensor:
+    """(C,1,3,3) depth-wise weight -> tap-major [9][C] (the layout cmk_dwconv3x3_nhwc reads)."""
+    c = weight.shape[0]
+    assert tuple(weight.shape) == (c, 1, 3, 3), "depth-wise 3x3 weight must be (C,1,3,3)"
+    return weight.detach().float().cpu().reshape(c, 9).t().contiguous()
+
+
+def dwconv3x3(x: View, w9c: torch.Tensor, y: Optional[View] = None, stride: int = 1) -> View:
+    """Depth-wise 3x3, pad 1, no bias / activation (vovnet.py:110-119)."""
+    lib = _lib.load()
+    n, h, w = x.nhw
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    if y is None:
+        y = View(torch.empty((n, ho, wo, x.c), dtype=torch.float32, device=x.t.device))
+    assert y.nhw == (n, ho, wo) and y.c == x.c and tuple(w9c.shape) == (9, x.c)
+    check(lib.cmk_dwconv3x3_nhwc(x.t.data_ptr(), x.cs, x.co, w9c.data_ptr(), y.t.data_ptr(), y.cs, y.co, n, h, w, x.c, stride, _stream()),
+          "cmk_dwconv3x3_nhwc")
+    return y
+
+
 def maxpool3x3s2_ceil(x: View, y: Optional[View] = None, gate: Optional[torch.Tensor] = None) -> View:
     lib = _lib.load()
     n, h, w = x.nhw

@@ -13,8 +13,12 @@ from typing import Dict, Iterable, Tuple
 
 import torch
 
-# vovnet.py:60-108 (non-depthwise specs)
+# vovnet.py:30-108
 STAGE_SPECS = {
+    "V-19-slim-dw-eSE": dict(stem=[64, 64, 64], stage_conv_ch=[64, 80, 96, 112], stage_out_ch=[112, 256, 384, 512],
+                             layer_per_block=3, block_per_stage=[1, 1, 1, 1], dw=True),
+    "V-19-dw-eSE": dict(stem=[64, 64, 64], stage_conv_ch=[128, 160, 192, 224], stage_out_ch=[256, 512, 768, 1024],
+                        layer_per_block=3, block_per_stage=[1, 1, 1, 1], dw=True),
     "V-19-slim-eSE": dict(stem=[64, 64, 128], stage_conv_ch=[64, 80, 96, 112], stage_out_ch=[112, 256, 384, 512],
                           layer_per_block=3, block_per_stage=[1, 1, 1, 1]),
     "V-19-eSE": dict(stem=[64, 64, 128], stage_conv_ch=[128, 160, 192, 224], stage_out_ch=[256, 512, 768, 1024],
@@ -41,11 +45,23 @@ def model_param_shapes(conv_body: str = "V-39-eSE", num_classes: int = 80, fpn_c
         for n in ("weight", "bias", "running_mean", "running_var"):
             s[prefix + "/norm." + n] = (cout,)
 
+    def dw_pw_bn(prefix: str, c: int) -> None:      # dw_conv3x3 vovnet.py:110-130
+        s[prefix + "/dw_conv3x3.weight"] = (c, 1, 3, 3)
+        s[prefix + "/pw_conv1x1.weight"] = (c, c, 1, 1)
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            s[prefix + "/pw_norm." + n] = (c,)
+
+    dw = spec.get("dw", False)
     bu = "backbone.bottom_up."
     stem = spec["stem"]
     conv_bn(bu + "stem.stem_1", 3, stem[0], 3)
-    conv_bn(bu + "stem.stem_2", stem[0], stem[1], 3)
-    conv_bn(bu + "stem.stem_3", stem[1], stem[2], 3)
+    if dw:
+        assert stem[0] == stem[1] == stem[2]
+        dw_pw_bn(bu + "stem.stem_2", stem[1])
+        dw_pw_bn(bu + "stem.stem_3", stem[2])
+    else:
+        conv_bn(bu + "stem.stem_2", stem[0], stem[1], 3)
+        conv_bn(bu + "stem.stem_3", stem[1], stem[2], 3)
     in_ch = stem[2]
     for si in range(4):
         stage_ch, concat_ch = spec["stage_conv_ch"][si], spec["stage_out_ch"][si]
@@ -53,8 +69,13 @@ def model_param_shapes(conv_body: str = "V-39-eSE", num_classes: int = 80, fpn_c
             mod = "OSA{}_{}".format(si + 2, b + 1)
             p = bu + "stage{}.{}.".format(si + 2, mod)
             cin = in_ch
+            if dw and in_ch != stage_ch:            # conv_reduction vovnet.py:284-288
+                conv_bn(p + "conv_reduction.{}_reduction_0".format(mod), in_ch, stage_ch, 1)
             for i in range(spec["layer_per_block"]):
-                conv_bn(p + "layers.{}.{}_{}".format(i, mod, i), cin, stage_ch, 3)
+                if dw:
+                    dw_pw_bn(p + "layers.{}.{}_{}".format(i, mod, i), stage_ch)
+                else:
+                    conv_bn(p + "layers.{}.{}_{}".format(i, mod, i), cin, stage_ch, 3)
                 cin = stage_ch
             conv_bn(p + "concat.{}_concat".format(mod), in_ch + spec["layer_per_block"] * stage_ch, concat_ch, 1)
             s[p + "ese.fc.weight"] = (concat_ch, concat_ch, 1, 1)
@@ -123,10 +144,12 @@ def synthetic_tensor(name: str, shape: Iterable[int], seed: int = 0) -> torch.Te
     leaf = name.rsplit(".", 1)[-1]
     if name.endswith("stem_1/norm.running_var"):
         return rand(0.5, 1.5) * 400.0                 # pixel-scale inputs (std ~20) are normalised by the first BN
-    if name.endswith("/norm.weight") or name.endswith("/norm.running_var"):
+    if name.endswith("norm.weight") or name.endswith("norm.running_var"):     # '/norm.' and the dw bodies' '/pw_norm.'
         return rand(0.5, 1.5)
-    if name.endswith("/norm.bias") or name.endswith("/norm.running_mean"):
+    if name.endswith("norm.bias") or name.endswith("norm.running_mean"):
         return randn(0.1)
+    if name.endswith("/dw_conv3x3.weight"):
+        return randn(1.0 / 3.0)                       # no ReLU between the dw and pw convs: unit gain
     if ".scales." in name:
         return rand(SYNTH["scale_lo"], SYNTH["scale_hi"])
     if "ese.fc.weight" in name:

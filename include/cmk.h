@@ -71,6 +71,12 @@ int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize);
 int cmk_conv_cout_pad(int Cout);
 int64_t cmk_wino_packed_floats(int Cout, int Cin);
 
+/* ---- depth-wise 3x3, pad 1, stride 1|2, no bias / norm / activation (vovnet.py:110-119 'dw_conv3x3', the dw half of the
+ * depth-wise VoVNet bodies V-19-slim-dw-eSE / V-19-dw-eSE vovnet.py:30-48).  x, y are NHWC channel-slice views
+ * (pixel stride *_cs, offset *_co floats); w is tap-major [9][C]. ------------------------------------------------ */
+int cmk_dwconv3x3_nhwc(const float* x, int x_cs, int x_co, const float* w, float* y, int y_cs, int y_co,
+                       int N, int H, int W, int C, int stride, void* stream);
+
 /* ---- stem_1: 3x3 stride-2 conv on the NCHW 3-channel image (vovnet.py:409), BN-folded, ReLU, NHWC out -------- */
 int cmk_stem_conv_nchw3(const float* x, const float* w /* [27][Cout] */, const float* scale, const float* shift,
                         float* y, int N, int H, int W, int Cout, void* stream);

@@ -58,8 +58,12 @@ def _lib():
 # --------------------------------------------------------------------------------------
 # VoVNetV2 (vovnet.py)
 # --------------------------------------------------------------------------------------
-# vovnet.py:60-108 (only the non-depthwise specs; dw variants are out of scope)
+# vovnet.py:30-108
 STAGE_SPECS = {
+    "V-19-slim-dw-eSE": dict(stem=[64, 64, 64], stage_conv_ch=[64, 80, 96, 112], stage_out_ch=[112, 256, 384, 512],
+                             layer_per_block=3, block_per_stage=[1, 1, 1, 1], dw=True),
+    "V-19-dw-eSE": dict(stem=[64, 64, 64], stage_conv_ch=[128, 160, 192, 224], stage_out_ch=[256, 512, 768, 1024],
+                        layer_per_block=3, block_per_stage=[1, 1, 1, 1], dw=True),
     "V-19-slim-eSE": dict(stem=[64, 64, 128], stage_conv_ch=[64, 80, 96, 112], stage_out_ch=[112, 256, 384, 512],
                           layer_per_block=3, block_per_stage=[1, 1, 1, 1]),
     "V-19-eSE": dict(stem=[64, 64, 128], stage_conv_ch=[128, 160, 192, 224], stage_out_ch=[256, 512, 768, 1024],
@@ -88,6 +92,16 @@ def conv_bn_relu(x, sd, prefix: str, name: str, stride: int, k: int) -> torch.Te
     return F.relu(x)
 
 
+def dw_conv_bn_relu(x, sd, prefix: str, name: str, stride: int) -> torch.Tensor:
+    """dw_conv3x3 (vovnet.py:110-130): depth-wise 3x3 (groups = channels, the stride sits here) -> point-wise 1x1 ->
+    FrozenBN -> ReLU; nothing between the two convs."""
+    w = sd[prefix + name + "/dw_conv3x3.weight"]
+    x = F.conv2d(x, w, None, stride=stride, padding=1, groups=w.shape[0])
+    x = F.conv2d(x, sd[prefix + name + "/pw_conv1x1.weight"], None)
+    x = frozen_bn(x, sd, prefix + name + "/pw_norm.")
+    return F.relu(x)
+
+
 def ese_module(x, sd, prefix: str) -> torch.Tensor:
     """eSEModule.forward vovnet.py:255-260 with Hsigmoid :243-244: x * relu6(fc(avgpool(x)) + 3) / 6."""
     g = F.adaptive_avg_pool2d(x, 1)
@@ -96,12 +110,19 @@ def ese_module(x, sd, prefix: str) -> torch.Tensor:
     return x * g
 
 
-def osa_module(x, sd, prefix: str, module_name: str, layers: int, identity: bool) -> torch.Tensor:
-    """_OSA_module.forward vovnet.py:310-332.  eSE is unconditional (:307,:327); identity add after eSE (:329-330)."""
+def osa_module(x, sd, prefix: str, module_name: str, layers: int, identity: bool, depthwise: bool = False) -> torch.Tensor:
+    """_OSA_module.forward vovnet.py:310-332.  eSE is unconditional (:307,:327); identity add after eSE (:329-330).
+    Depth-wise bodies: a 1x1 'conv_reduction' to stage_ch first when in_ch != stage_ch (:284-288, :317-318); the
+    concat still starts with the un-reduced input (:315)."""
     identity_feat = x
     output = [x]
+    if depthwise and (prefix + "conv_reduction.{}_reduction_0/conv.weight".format(module_name)) in sd:
+        x = conv_bn_relu(x, sd, prefix + "conv_reduction.", module_name + "_reduction_0", 1, 1)
     for i in range(layers):
-        x = conv_bn_relu(x, sd, prefix + "layers.{}.".format(i), "{}_{}".format(module_name, i), 1, 3)
+        if depthwise:
+            x = dw_conv_bn_relu(x, sd, prefix + "layers.{}.".format(i), "{}_{}".format(module_name, i), 1)
+        else:
+            x = conv_bn_relu(x, sd, prefix + "layers.{}.".format(i), "{}_{}".format(module_name, i), 1, 3)
         output.append(x)
     x = torch.cat(output, dim=1)
     xt = conv_bn_relu(x, sd, prefix + "concat.", module_name + "_concat", 1, 1)
@@ -117,10 +138,15 @@ def vovnet_forward(sd, x: torch.Tensor, conv_body: str = "V-39-eSE",
     """VoVNet.forward vovnet.py:471-481; stem :409-411 (strides 2,1,2); stages :335-376 with
     MaxPool2d(3, 2, ceil_mode=True) in front of stages 3-5 (:349-350)."""
     spec = STAGE_SPECS[conv_body]
+    dw = spec.get("dw", False)
     outputs = {}
     x = conv_bn_relu(x, sd, prefix + "stem.", "stem_1", 2, 3)
-    x = conv_bn_relu(x, sd, prefix + "stem.", "stem_2", 1, 3)
-    x = conv_bn_relu(x, sd, prefix + "stem.", "stem_3", 2, 3)
+    if dw:   # vovnet.py:408-411: stem_2/stem_3 are dw_conv3x3 in the depth-wise bodies
+        x = dw_conv_bn_relu(x, sd, prefix + "stem.", "stem_2", 1)
+        x = dw_conv_bn_relu(x, sd, prefix + "stem.", "stem_3", 2)
+    else:
+        x = conv_bn_relu(x, sd, prefix + "stem.", "stem_2", 1, 3)
+        x = conv_bn_relu(x, sd, prefix + "stem.", "stem_3", 2, 3)
     if "stem" in out_features:
         outputs["stem"] = x
     for si in range(4):
@@ -131,7 +157,7 @@ def vovnet_forward(sd, x: torch.Tensor, conv_body: str = "V-39-eSE",
         for b in range(spec["block_per_stage"][si]):
             module_name = "OSA{}_{}".format(stage_num, b + 1)
             x = osa_module(x, sd, prefix + "{}.{}.".format(name, module_name), module_name,
-                           spec["layer_per_block"], identity=(b > 0))
+                           spec["layer_per_block"], identity=(b > 0), depthwise=dw)
         if name in out_features:
             outputs[name] = x
     return outputs

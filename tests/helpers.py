@@ -26,7 +26,7 @@ def build_gpu_model(conv_body="V-39-eSE", seed=0):
     from centermask2_amd.modeling import build_model
     from centermask2_amd import synthetic as S
     cfg = get_cfg()
-    name = "centermask_V_39_eSE_FPN_ms_3x.yaml" if conv_body == "V-39-eSE" else "centermask_V_99_eSE_FPN_ms_3x.yaml"
+    name = "centermask_V_99_eSE_FPN_ms_3x.yaml" if conv_body == "V-99-eSE" else "centermask_V_39_eSE_FPN_ms_3x.yaml"
     cfg.merge_from_file(config_path(name))
     cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.VOVNET.CONV_BODY", conv_body])
     cfg.freeze()

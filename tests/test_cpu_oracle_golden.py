@@ -32,6 +32,20 @@ def test_backbone_fpn_small():
         close(out[k], g[k], 1e-6, k)
 
 
+def test_other_vovnet_bodies_incl_depthwise():
+    """V-19-slim-dw / V-19-dw (dw_conv3x3 + conv_reduction, vovnet.py:110-130,284-288) and V-19-slim."""
+    g = golden("vovnet_bodies")
+    assert set(g.keys()) == {"V-19-slim-dw-eSE", "V-19-dw-eSE", "V-19-slim-eSE"}
+    for body, case in g.items():
+        sd = S.make_synthetic_state_dict(body, 0)
+        out = O.vovnet_forward(sd, case["x"], conv_body=body)
+        for k in ("stage3", "stage4", "stage5"):
+            close(out[k], case[k], 1e-6, body + " " + k)
+        out = O.backbone_forward(sd, case["x32"], conv_body=body)
+        for k in ("p3", "p4", "p5", "p6", "p7"):
+            close(out[k], case[k], 1e-6, body + " " + k)
+
+
 def test_fcos_head_decode_nms_small():
     g, bb = golden("fcos_small"), golden("backbone_small")
     sd = dict(_sd())

@@ -82,6 +82,22 @@ def test_conv_rejects_bad_arguments(dev, cmk_lib):
         ops.conv2d(View(x, 0, 24), pc, View(torch.zeros((1, 4, 4, 8), device=dev)))
 
 
+@pytest.mark.parametrize("case", [(2, 37, 53, 64, 1), (1, 40, 64, 112, 2), (3, 9, 7, 80, 1), (1, 1, 1, 4, 2), (2, 30, 31, 96, 2)])
+def test_depthwise_conv3x3(dev, case):
+    n, h, w, c, stride = case
+    g = torch.Generator().manual_seed(5)
+    buf = torch.randn((n, h, w, c + 16), generator=g).to(dev)            # read a channel slice of a wider buffer
+    wt = torch.randn((c, 1, 3, 3), generator=g)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    ybuf = torch.full((n, ho, wo, c + 8), 7.0, device=dev)
+    y = ops.dwconv3x3(View(buf, 8, c), ops.pack_dw_weight(wt).to(dev), View(ybuf, 4, c), stride=stride)
+    torch.cuda.synchronize()
+    ref = F.conv2d(buf[..., 8:8 + c].permute(0, 3, 1, 2).cpu(), wt, None, stride=stride, padding=1, groups=c).permute(0, 2, 3, 1)
+    _close(ybuf[..., 4:4 + c], ref, 1e-5)
+    assert float(ybuf[..., :4].min()) == 7.0 and float(ybuf[..., 4 + c:].max()) == 7.0   # neighbours untouched
+    assert y.c == c
+
+
 def test_stem_conv(dev):
     x = _rand((2, 3, 37, 50), 11, 40.0)
     wt = _rand((64, 3, 3, 3), 12, 0.2)

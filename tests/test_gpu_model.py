@@ -33,6 +33,22 @@ def test_backbone_fpn_matches_reference(dev, model):
     assert shp["p3"].stride == 8 and shp["p7"].stride == 128 and shp["p5"].channels == 256 and model.backbone.size_divisibility == 32
 
 
+@pytest.mark.parametrize("body", ["V-19-slim-dw-eSE", "V-19-dw-eSE", "V-19-slim-eSE"])
+def test_other_vovnet_bodies_match_reference(dev, body):
+    """the depth-wise bodies (dw 3x3 kernel + 1x1, conv_reduction) and the slim channel counts."""
+    g = golden("vovnet_bodies")[body]
+    m = build_gpu_model(body)[0]
+    out = m.backbone.bottom_up(g["x"].to(dev))
+    torch.cuda.synchronize()
+    for k in ("stage3", "stage4", "stage5"):
+        assert tuple(out[k].shape) == tuple(g[k].shape)
+        close(out[k], g[k], 1e-4, body + " " + k)
+    out = m.backbone(g["x32"].to(dev))
+    torch.cuda.synchronize()
+    for k in ("p3", "p4", "p5", "p6", "p7"):
+        close(out[k], g[k], 1e-4, body + " " + k)
+
+
 def test_fcos_head_matches_reference(dev, model):
     g, bb = golden("fcos_small"), golden("backbone_small")
     feats = [bb[k].to(dev) for k in ("p3", "p4", "p5", "p6", "p7")]
