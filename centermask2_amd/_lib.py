@@ -25,6 +25,7 @@ class ConvDesc(Structure):
         ("tune_wm", c_int), ("tune_sc", c_int), ("tune_wn", c_int),
         ("w_wino", c_void_p),
         ("in_scale", c_void_p), ("in_shift", c_void_p),
+        ("splitk", c_int), ("splitk_ws", c_void_p),
     ]
 
 

@@ -59,6 +59,9 @@ struct ConvArgs {
     int relu_upto, in_relu;
     int cout_pad;
     int total_tiles;   // spatial tiles of all problems (XCD-aware kernels pad the grid to a multiple of 8 tiles)
+    int ksplit;        // split-K: blockIdx.y owns an (even) range of the 16-channel chunks and writes raw partial sums to ws
+    float* ws;         // [ksplit][total_pix][cout_pad]
+    int ga_stride;     // gather form (GA): stride of the 3x3 conv whose taps are walked as 9x more K chunks
     int grid_y;   // N tiles; the N-tile index is the FASTEST block coordinate so the workgroups sharing an input tile run together (L2 reuse)
 };
 
@@ -83,7 +86,10 @@ struct Geo {
     static constexpr int B_ITERS = (BN * 4 + 255) / 256;
 };
 
-template <int TAPS, int STRIDE, int WM, int WN, int SC>
+// GA ("gather") form: a 3x3 conv run as a flattened-pixel GEMM (TAPS == 1 geometry) whose K walks 9 taps x Cin/16 chunks; each
+// thread gathers its A rows per tap straight from the image (zero outside).  No halo reuse, so it only pays on maps too small
+// to fill the spatial tiles (7x7 RoI maps, P6/P7).
+template <int TAPS, int STRIDE, int WM, int WN, int SC, bool GA = false>
 __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kernel(const ConvArgs a) {
     using G = Geo<TAPS, STRIDE, WM, WN, SC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -122,12 +128,15 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
         pix0 = (long)tile * G::BM;
     }
     const int co0 = by * G::BN;
-    const int nchunks = a.Cin >> 4;
-    const int total_steps = nchunks * TAPS;
+    const int cin_chunks = a.Cin >> 4;
+    const int nchunks = GA ? 9 * cin_chunks : cin_chunks;
+    const int c_lo = (int)((long)blockIdx.y * nchunks / a.ksplit), c_hi = (int)((long)(blockIdx.y + 1) * nchunks / a.ksplit);  // even bounds (host)
+    const int total_steps = c_hi * TAPS;
 
     // ---- per-thread staging descriptors ------------------------------------------------------------------------
     const float* xin = P.x + (TAPS == 9 ? (long)n * H * W * a.x_cs : 0L) + a.x_co;
     long a_goff[G::A_ITERS];   // clamped to a valid address; a_ok tells whether the value is used
+    int ga_ih0[GA ? G::A_ITERS : 1], ga_iw0[GA ? G::A_ITERS : 1];   // GA: top-left input coordinate of the row's 3x3 window
     unsigned a_ok = 0;
 #pragma unroll
     for (int it = 0; it < G::A_ITERS; ++it) {
@@ -135,7 +144,18 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
         int pix = idx >> 2, q = idx & 3;
         long off = 0;
         if (idx < G::APIX * 4) {
-            if (TAPS == 9) {
+            if (GA) {
+                long Pp = pix0 + pix;
+                const bool pv = Pp < total_pix;
+                if (!pv) Pp = 0;
+                const long hw = (long)Ho * Wo;
+                const int n_ = (int)(Pp / hw);
+                const int rem = (int)(Pp - (long)n_ * hw);
+                const int oh = rem / Wo, ow = rem - oh * Wo;
+                ga_ih0[it] = pv ? oh * a.ga_stride - 1 : -4;      // -4: every tap lands outside
+                ga_iw0[it] = ow * a.ga_stride - 1;
+                off = (long)n_ * H * W * a.x_cs + q * 4;
+            } else if (TAPS == 9) {
                 int hr = pix / G::HWD, hc = pix - hr * G::HWD;
                 int ih = oh0 * STRIDE - 1 + hr, iw = ow0 * STRIDE - 1 + hc;
                 if (ih >= 0 && ih < H && iw >= 0 && iw < W) { off = ((long)ih * W + iw) * a.x_cs + q * 4; a_ok |= 1u << it; }
@@ -157,6 +177,20 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
     f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
 
     auto load_A = [&](int chunk) {
+        if (GA) {
+            const int tap = chunk / cin_chunks, ch = chunk - tap * cin_chunks;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            a_ok = 0;
+#pragma unroll
+            for (int it = 0; it < G::A_ITERS; ++it) {
+                const int ih = ga_ih0[it] + kh, iw = ga_iw0[it] + kw;
+                const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                const long off = ok ? a_goff[it] + ((long)ih * W + iw) * a.x_cs + ch * 16 : 0L;
+                a_stage[it] = *reinterpret_cast<const f32x4*>(xin + off);
+                a_ok |= (ok ? 1u : 0u) << it;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < G::A_ITERS; ++it) a_stage[it] = *reinterpret_cast<const f32x4*>(xin + a_goff[it] + chunk * 16);
         if (has_aff) {
@@ -228,14 +262,14 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
 
     // ---- prologue ---------------------------------------------------------------------------------------------------
-    load_A(0);
-    load_B(0);
-    store_A(0);
+    load_A(c_lo);
+    load_B(c_lo * TAPS);
+    store_A(0);          // c_lo is even, so buffer parity (c & 1, step & 1) starts at 0
     store_B(0);
 
-    int step = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        const bool has_next_chunk = (c + 1 < nchunks);
+    int step = c_lo * TAPS;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const bool has_next_chunk = (c + 1 < c_hi);
         if (has_next_chunk) load_A(c + 1);
         const float* Abase = sA + (G::ADB ? (c & 1) : 0) * (G::APIX * PST);
 #pragma unroll 1
@@ -278,6 +312,34 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
                 store_A(G::ADB ? ((c + 1) & 1) : 0);
             }
         }
+    }
+
+    // ---- split-K: raw partial sums to the workspace, the reduce kernel applies the epilogue ----------------------------
+    if (a.ksplit > 1) {
+        float* wz = a.ws + (long)blockIdx.y * total_pix * a.cout_pad + co0 + li;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const int u = wave * WM + m;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                long opix;
+                bool pvalid;
+                if (TAPS == 9) {
+                    const int oh = oh0 + u * G::SR + row / SC, ow = ow0 + row % SC;
+                    pvalid = (oh < Ho) && (ow < Wo);
+                    opix = ((long)n * Ho + oh) * Wo + ow;
+                } else {
+                    opix = pix0 + u * 32 + row;
+                    pvalid = opix < total_pix;
+                }
+                if (pvalid) {
+#pragma unroll
+                    for (int nn = 0; nn < WN; ++nn) wz[opix * a.cout_pad + nn * 32] = acc[m][nn][r];
+                }
+            }
+        }
+        return;
     }
 
     // ---- epilogue: scale/shift (+residual) (+ReLU), NHWC store -------------------------------------------------------
@@ -325,6 +387,36 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
                     if (do_relu) v = fmaxf(v, 0.f);
                     P.y[opix * a.y_cs + a.y_co + co] = v;
                 }
+            }
+        }
+    }
+}
+
+
+// split-K second pass: y = epilogue(sum_z ws[z]); one thread = 4 couts of one pixel
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, long total_pix, int cout_pad,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int Cout,
+                                                           int relu_upto, const float* __restrict__ res, int res_cs, int res_co,
+                                                           float* __restrict__ y, int y_cs, int y_co) {
+    const int c4n = cout_pad >> 2;
+    const long total = total_pix * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pix = i / c4n;
+        const int co = (int)(i - pix * c4n) * 4;
+        if (co >= Cout) continue;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < ksplit; ++z) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((long)z * total_pix + pix) * cout_pad + co);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = co + j;
+            if (c < Cout) {
+                float v = s[j] * scale[c] + shift[c];
+                if (res) v += res[pix * res_cs + res_co + c];
+                if (c < relu_upto) v = fmaxf(v, 0.f);
+                y[pix * y_cs + y_co + c] = v;
             }
         }
     }
@@ -855,11 +947,11 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------
 struct Variant { int wm, sc, wn; };
 
-template <int TAPS, int STRIDE, int WM, int WN, int SC>
+template <int TAPS, int STRIDE, int WM, int WN, int SC, bool GA = false>
 static int launch(ConvArgs& a, int grid_y, hipStream_t st) {
     using G = Geo<TAPS, STRIDE, WM, WN, SC>;
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>;
+    auto kern = conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC, GA>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            G::LDS_BYTES);
@@ -881,8 +973,18 @@ static int launch(ConvArgs& a, int grid_y, hipStream_t st) {
     }
     a.grid_y = grid_y;
     a.total_tiles = blocks;
-    hipLaunchKernelGGL(kern, dim3(((blocks + 7) / 8) * 8 * grid_y), dim3(256), G::LDS_BYTES, st, a);
-    return check_launch("conv_igemm");
+    if (a.ksplit < 1) a.ksplit = 1;
+    const int vchunks = (GA ? 9 : 1) * (a.Cin >> 4);
+    if (a.ksplit > 1 && (a.nprob != 1 || a.res_mode == 2 || !a.ws || vchunks % (2 * a.ksplit)))
+        return fail(CMK_EINVAL, "conv: split-K needs one problem, a workspace, no upsampled residual and K chunks %% (2*splitk) == 0%s", "");
+    hipLaunchKernelGGL(kern, dim3(((blocks + 7) / 8) * 8 * grid_y, a.ksplit), dim3(256), G::LDS_BYTES, st, a);
+    int rc = check_launch("conv_igemm");
+    if (rc || a.ksplit == 1) return rc;
+    const ConvProblem& p = a.p[0];
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((p.total_pix * (a.cout_pad >> 2) + 255) / 256, 256L * 32)), dim3(256), 0, st, a.ws, a.ksplit, p.total_pix,
+                       a.cout_pad, p.scale, p.shift, a.Cout, a.relu_upto, a.res_mode == 1 ? a.res : nullptr, a.res_cs, a.res_co, p.y, a.y_cs,
+                       a.y_co);
+    return check_launch("splitk_reduce");
 }
 
 // cost of running `blocks` equal workgroups with `resident` per CU on 256 CUs: full rounds keep every CU at `resident`
@@ -1013,8 +1115,22 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     if (d->tune_wm == 4 || d->tune_wm == 6) {          // Winograd F(2x2,3x3) (4 = 8 waves / 1 workgroup per CU, 6 = 4 waves x 2 workgroups per CU): 3x3 stride 1, no residual / input ReLU
         if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino || (d->in_scale && d->tune_wm != 6))
             return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
+        if (d->splitk > 1) return fail(CMK_EINVAL, "conv: split-K is a direct-kernel feature%s", "");
         a.w = d->w_wino;
         return launch_wino(a, d->tune_wm - 3, st);
+    }
+    a.ksplit = d->splitk > 1 ? d->splitk : 1;
+    a.ws = d->splitk_ws;
+    if (d->tune_wm == 7) {                             // gather form: 3x3 (stride 1|2) as a flattened-pixel GEMM over 9x the K chunks
+        if (d->ksize != 3 || n != 1 || d->res_mode == 2 || d->in_scale || (d->tune_wn != 1 && d->tune_wn != 2 && d->tune_wn != 4))
+            return fail(CMK_EINVAL, "conv: gather variant not available for this conv%s", "");
+        const int cout_pad32 = cout32 <= 7 ? cout32 : cdiv(cout32, 4) * 4;
+        if (cout_pad32 % d->tune_wn) return fail(CMK_EINVAL, "conv: gather variant: Cout tiles %% WN != 0%s", "");
+        a.cout_pad = cout_pad32 * 32;
+        a.ga_stride = d->stride;
+        const int gy = cout_pad32 / d->tune_wn;
+        return d->tune_wn == 4 ? launch<1, 1, 1, 4, 32, true>(a, gy, st) : d->tune_wn == 2 ? launch<1, 1, 1, 2, 32, true>(a, gy, st)
+                                                                                           : launch<1, 1, 1, 1, 32, true>(a, gy, st);
     }
     Variant v;
     if (d->tune_wm || d->tune_sc || d->tune_wn) {      // the caller measured and picked a variant
@@ -1023,9 +1139,19 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     } else {
         // untuned default: the 2-WG/CU Winograd form wins on every 3x3 stride-1 shape measured (tools/bench_wino.py), so take it
         // whenever the caller packed the transformed weights; otherwise the direct-kernel cost model decides
-        if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && d->w_wino && d->Cin >= 32) {
+        if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && d->w_wino && d->Cin >= 32 && d->splitk <= 1) {
             a.w = d->w_wino;
             return launch_wino(a, 3, st);
+        }
+        // stride-2 3x3 on a map of at most 16x16 outputs (maskiou conv4 14->7, P6/P7): the spatial tiles would be mostly empty
+        if (d->ksize == 3 && d->stride == 2 && n == 1 && d->res_mode != 2 && !d->in_scale && a.p[0].Ho <= 16 && a.p[0].Wo <= 16) {
+            const int cout_pad32 = cout32 <= 7 ? cout32 : cdiv(cout32, 4) * 4;
+            const int wn = (cout_pad32 % 4 == 0 && a.p[0].total_pix >= 8192) ? 4 : (cout_pad32 % 2 == 0 && a.p[0].total_pix >= 2048) ? 2 : 1;
+            a.cout_pad = cout_pad32 * 32;
+            a.ga_stride = 2;
+            const int gy = cout_pad32 / wn;
+            return wn == 4 ? launch<1, 1, 1, 4, 32, true>(a, gy, st) : wn == 2 ? launch<1, 1, 1, 2, 32, true>(a, gy, st)
+                                                                               : launch<1, 1, 1, 1, 32, true>(a, gy, st);
         }
         v = choose_variant(a, taps, d->stride, cout32);
     }

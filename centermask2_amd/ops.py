@@ -196,46 +196,81 @@ def load_tuned(path: str) -> int:
     return len(table)
 
 
+def _out_pixels(d) -> int:
+    ho = d.H if d.stride == 1 else (d.H - 1) // 2 + 1
+    wo = d.W if d.stride == 1 else (d.W - 1) // 2 + 1
+    return d.N * ho * wo
+
+
+def _set_variant(descs, n, tv):
+    """Write a (wm, sc, wn[, splitk]) choice into the descriptors; returns the split-K workspace (keep it alive until the launch)."""
+    wm, sc, wn = tv[:3]
+    sk = tv[3] if len(tv) > 3 else 1
+    for i in range(n):
+        descs[i].tune_wm, descs[i].tune_sc, descs[i].tune_wn = wm, sc, wn
+        descs[i].splitk, descs[i].splitk_ws = 0, None
+    ws = None
+    if sk > 1:
+        d = descs[0]
+        ws = torch.empty((sk * _out_pixels(d) * _lib.load().cmk_conv_cout_pad(d.Cout),), dtype=torch.float32, device="cuda")
+        d.splitk, d.splitk_ws = sk, ws.data_ptr()
+    return ws
+
+
 def _tune(descs, n, key) -> None:
-    """Time every available (wm, sc, wn) variant on the real buffers (results are bitwise identical across variants)
-    and remember the fastest.  Variants the library rejects for this shape are skipped."""
+    """Time every available (wm, sc, wn, splitk) variant on the real buffers and remember the fastest.  The direct variants
+    (incl. the gather form and split-K, whose K order is unchanged up to the final sum) agree to rounding; variants the
+    library rejects for this shape are skipped."""
     lib = _lib.load()
     st = _stream()
+    d0 = descs[0]
 
     def run():
         return lib.cmk_conv2d_nhwc_multi(descs, n, st) if n > 1 else lib.cmk_conv2d_nhwc(ctypes.byref(descs[0]), st)
 
     best, best_ms = (0, 0, 0), float("inf")
-    cands = [(wm, sc, wn) for wn in range(1, 8) for wm in (1, 2) for sc in (16, 32)]
+    small = n == 1 and d0.res_mode != 2 and _out_pixels(d0) <= 32768      # few M tiles: split-K / gather forms can pay
+    sks = (1, 2, 4, 8) if small else (1,)
+    cands = [(wm, sc, wn, sk) for wn in range(1, 8) for wm in (1, 2) for sc in (16, 32) for sk in sks]
+    if small and d0.ksize == 3:
+        cands += [(7, 32, wn, sk) for wn in (1, 2, 4) for sk in sks]      # gather form
     if ALLOW_WINOGRAD:
-        cands += [(4, 16, 2), (6, 16, 2)]         # fused Winograd F(2x2,3x3): 8-wave / 1 WG per CU and 4-wave / 2 WG per CU forms
-    for wm, sc, wn in cands:
-        for _once in (0,):
-            for _once2 in (0,):
-                for i in range(n):
-                    descs[i].tune_wm, descs[i].tune_sc, descs[i].tune_wn = wm, sc, wn
-                if run() != 0:
-                    continue                      # not on the menu for this shape
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                run()
-                run()
-                e1.record()
-                e1.synchronize()
-                ms = e0.elapsed_time(e1)
-                if ms < best_ms:
-                    best, best_ms = (wm, sc, wn), ms
+        cands += [(4, 16, 2, 1), (6, 16, 2, 1)]   # fused Winograd F(2x2,3x3): 8-wave / 1 WG per CU and 4-wave / 2 WG per CU forms
+    for tv in cands:
+        ws = _set_variant(descs, n, tv)
+        if run() != 0:
+            continue                              # not on the menu for this shape
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run()
+        run()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if ms < best_ms:
+            best, best_ms = (tv[:3] if tv[3] == 1 else tv), ms
+        del ws
     _TUNED[key] = best
 
 
-def _apply_tuning(descs, n, key) -> None:
+def _default_variant(d):
+    """No table entry and no tuner: library defaults, plus split-K for skinny 1x1 GEMMs (maskiou_fc1: 400 x 12544 x 1024)."""
+    if d.ksize == 1 and d.res_mode != 2 and _out_pixels(d) <= 1024 and d.Cin >= 4096:
+        chunks = d.Cin // 16
+        for sk in (4, 2):
+            if chunks % (2 * sk) == 0:
+                return (0, 0, 0, sk)
+    return (0, 0, 0)
+
+
+def _apply_tuning(descs, n, key):
     tv = _TUNED.get(key)
     if tv is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
         _tune(descs, n, key)
         tv = _TUNED[key]
-    tv = tv or (0, 0, 0)
-    for i in range(n):
-        descs[i].tune_wm, descs[i].tune_sc, descs[i].tune_wn = tv
+    if tv is None:
+        tv = _default_variant(descs[0]) if n == 1 else (0, 0, 0)
+    return _set_variant(descs, n, tv)
 
 
 def _problem_key(descs, n):
@@ -250,8 +285,9 @@ def conv2d(x: View, pc: PackedConv, y: View, relu: bool = False, relu_upto: Opti
     lib = _lib.load()
     descs = (ConvDesc * 1)()
     _fill_desc(descs[0], x, pc, y, relu, relu_upto, res, res_upsample, in_relu)
-    _apply_tuning(descs, 1, _problem_key(descs, 1))
+    ws = _apply_tuning(descs, 1, _problem_key(descs, 1))      # split-K workspace (if any) stays referenced across the launch
     check(lib.cmk_conv2d_nhwc(ctypes.byref(descs[0]), _stream()), "cmk_conv2d_nhwc")
+    del ws
 
 
 def conv2d_multi(xs: Sequence[View], pcs: Sequence[PackedConv], ys: Sequence[View], relu: bool = False,
@@ -264,8 +300,9 @@ def conv2d_multi(xs: Sequence[View], pcs: Sequence[PackedConv], ys: Sequence[Vie
     for i in range(n):
         assert pcs[i].w.data_ptr() == pcs[0].w.data_ptr()
         _fill_desc(descs[i], xs[i], pcs[i], ys[i], relu, relu_upto, None, False, False, in_affine[i] if in_affine is not None else None)
-    _apply_tuning(descs, n, _problem_key(descs, n))
+    ws = _apply_tuning(descs, n, _problem_key(descs, n))
     check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi")
+    del ws
 
 
 def conv_out_multi(xs: Sequence[View], pcs: Sequence[PackedConv], **kw) -> List[View]:  # kw: relu, relu_upto, in_affine
@@ -542,11 +579,13 @@ _conv2d_plain = conv2d
 
 def _kernel_name(taps, stride, tv) -> str:
     """The template instantiation rocprofv3 will report: conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>."""
-    if not tv or tv == (0, 0, 0):
+    if not tv or tuple(tv[:3]) == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
     if tv[0] in (4, 6):
         return "cmk::conv_wino{}_kernel".format({4: "8", 6: "4s"}[tv[0]])
-    wm, sc, wn = tv
+    wm, sc, wn = tv[:3]
+    if wm == 7:
+        return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)
     return "conv_igemm_kernel<{}, {}, {}, {}, {}>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
 
 

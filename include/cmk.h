@@ -47,7 +47,10 @@ typedef struct {
     /* optional tile variant picked by the caller's autotuner (all 0 = let the library's cost model choose):
      * tune_wm in {1,2} (128 or 256 pixels per workgroup), tune_sc in {16,32} (sub-tile 2x16 or 1x32 pixels; 32 for 1x1),
      * tune_wn in 1..7 (32*tune_wn output channels per workgroup; must divide the padded Cout).  Results are bitwise
-     * identical across variants (the K order per output does not depend on the tile). */
+     * identical across variants (the K order per output does not depend on the tile).
+     * tune_wm == 7 (with tune_wn in {1,2,4}) selects the gather form of a 3x3 conv (stride 1|2): a flattened-pixel GEMM whose K walks
+     * 9 taps x Cin/16 chunks, each A row gathered per tap — for maps too small to fill the spatial tiles (the 14->7 maskiou conv
+     * maskiou_head.py:84, P6/P7 fpn.py:32-35); same K order, so again bitwise identical to the tiled variants. */
     int tune_wm; int tune_sc; int tune_wn;
     /* tune_wm == 6 (4 waves, two workgroups per CU; the default for 3x3 stride 1) or 4 (8 waves, one workgroup per CU) selects the
      * fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual): same fp32 arithmetic on the
@@ -60,6 +63,11 @@ typedef struct {
      * is applied while the input tile is staged, so the normalised tensor is never written; arrays of N*Cin floats from
      * cmk_groupnorm_affine.  Supported by the direct kernels and Winograd form 6. */
     const float* in_scale; const float* in_shift;
+    /* split-K (direct kernels incl. the gather form, one problem, res_mode 0|1): splitk >= 2 workgroup rows each own 1/splitk of the
+     * 16-channel K chunks (K chunks % (2*splitk) == 0) and write raw partial sums to splitk_ws (splitk * N*Ho*Wo * cmk_conv_cout_pad(Cout)
+     * floats, caller-owned); a second launch sums them and applies the epilogue.  For skinny GEMMs (maskiou_fc1: 400 x 12544 x 1024,
+     * maskiou_head.py:116) whose M x N tiles cannot fill 256 CUs.  0/1 = off. */
+    int splitk; float* splitk_ws;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
 /* Same conv applied to up to 5 inputs of different H x W in ONE launch (the FCOS towers/predictors share their weights

@@ -213,6 +213,62 @@ def test_conv_winograd_variant(dev, case, waves):
     _close(y.nchw(), ref)
 
 
+GATHER_SPLITK_CASES = [
+    # N, H, W, Cin, Cout, k, stride, (wm, sc, wn, splitk), residual
+    (3, 14, 14, 272, 256, 3, 2, (7, 32, 4, 1), False),    # maskiou conv4 class, gather form
+    (3, 14, 14, 256, 256, 3, 2, (7, 32, 2, 2), False),    # + split-K
+    (2, 13, 20, 256, 256, 3, 2, (7, 32, 1, 4), False),    # P7 class
+    (2, 9, 11, 64, 96, 3, 1, (7, 32, 1, 1), True),        # gather form at stride 1 with a same-size residual
+    (2, 14, 14, 272, 256, 3, 2, (0, 0, 0, 1), False),     # library default picks the gather form for tiny stride-2 maps
+    (1, 1, 37, 12544, 1024, 1, 1, (1, 32, 1, 4), False),  # maskiou_fc1 as split-K GEMM
+    (1, 1, 400, 1024, 80, 1, 1, (0, 0, 0, 2), True),      # split-K with the cost-model variant + residual
+    (1, 16, 16, 64, 64, 3, 1, (1, 16, 2, 2), False),      # split-K on the tiled 3x3 kernel
+]
+
+
+@pytest.mark.parametrize("case", GATHER_SPLITK_CASES)
+def test_conv_gather_form_and_split_k(dev, case):
+    import ctypes
+    from centermask2_amd import _lib
+    n, h, w, cin, cout, k, stride, tv, with_res = case
+    x = _rand((n, cin, h, w), 61)
+    wt = _rand((cout, cin, k, k), 62, (2.0 / (cin * k * k)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(63)) + 0.5
+    shift = _rand((cout,), 64, 0.1)
+    ref = F.conv2d(x, wt, None, stride=stride, padding=k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = _rand(tuple(ref.shape), 65) if with_res else None
+    if with_res:
+        ref = ref + res
+    ref = F.relu(ref)
+    pc = ops.PackedConv(wt, scale, shift, dev, stride=stride)
+    pc.w_wino = None                                   # keep the default on the direct kernels
+    xv = ops.as_view(x.to(dev))
+    y = View(torch.full((n, ref.shape[2], ref.shape[3], cout), -5.0, device=dev))
+    d = (_lib.ConvDesc * 1)()
+    resv = ops.as_view(res.to(dev)) if with_res else None      # the descriptor only borrows the pointer: keep the tensor alive
+    ops._fill_desc(d[0], xv, pc, y, True, None, resv, False, False)
+    ws = ops._set_variant(d, 1, tv)
+    _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "gather/split-K")
+    torch.cuda.synchronize()
+    del ws
+    _close(y.nchw(), ref)
+
+
+def test_conv_split_k_rejects_bad_requests(dev, cmk_lib):
+    import ctypes
+    from centermask2_amd import _lib
+    x = ops.as_view(_rand((1, 48, 8, 8), 1).to(dev))
+    pc = ops.PackedConv(_rand((32, 48, 1, 1), 2), None, None, dev)
+    y = View(torch.empty((1, 8, 8, 32), device=dev))
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], x, pc, y, False, None, None, False, False)
+    ws = ops._set_variant(d, 1, (0, 0, 0, 2))          # 3 K chunks are not divisible by 2*2
+    assert cmk_lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0 and b"split-K" in cmk_lib.cmk_last_error()
+    d[0].splitk, d[0].splitk_ws = 2, None              # no workspace
+    assert cmk_lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
+    del ws
+
+
 @pytest.mark.parametrize("variant", [(0, 0, 0), (6, 16, 2), (1, 16, 1)])
 def test_conv_fused_groupnorm_relu_input(dev, variant):
     """conv(relu(GroupNorm(x))) with the GN apply fused into the conv's input staging (direct kernels and Winograd form 6)."""
