@@ -26,6 +26,7 @@ class ConvDesc(Structure):
         ("w_wino", c_void_p),
         ("in_scale", c_void_p), ("in_shift", c_void_p),
         ("splitk", c_int), ("splitk_ws", c_void_p),
+        ("gn_ws", c_void_p), ("gn_groups", c_int),
     ]
 
 
@@ -52,6 +53,9 @@ SIGNATURES = {
     "cmk_groupnorm_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "cmk_groupnorm_affine_multi": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                            POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
+    "cmk_groupnorm_affine_tiles": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                           POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
+    "cmk_conv_gn_tiles": (c_int, [c_int, c_int]),
     "cmk_fcos_select": (c_int, [POINTER(FcosLevel), c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "cmk_fcos_select_ws_len": (c_int64, [POINTER(FcosLevel), c_int, c_int, c_int]),

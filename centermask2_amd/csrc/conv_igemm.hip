@@ -61,6 +61,8 @@ struct ConvArgs {
     int total_tiles;   // spatial tiles of all problems (XCD-aware kernels pad the grid to a multiple of 8 tiles)
     int ksplit;        // split-K: blockIdx.y owns an (even) range of the 16-channel chunks and writes raw partial sums to ws
     float* ws;         // [ksplit][total_pix][cout_pad]
+    double* gn_ws;     // Winograd 2-WG form: per (spatial tile, row parity, group) partial {sum, sum of squares} of the outputs (fused GroupNorm statistics)
+    int gn_cpg, gn_groups;
     int ga_stride;     // gather form (GA): stride of the 3x3 conv whose taps are walked as 9x more K chunks
     int grid_y;   // N tiles; the N-tile index is the FASTEST block coordinate so the workgroups sharing an input tile run together (L2 reuse)
 };
@@ -903,6 +905,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     // only the 8*hh column shift and the channel are per lane -> one lane base pointer, scalar offsets
     const int ow_l = ow0 + 8 * hh;
     float* ybase = P.y + (((long)n * H + oh0 + fh) * W + ow_l) * a.y_cs + a.y_co + co;
+    float gs = 0.f, gss = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ty = r >> 2, txr = r & 3;
@@ -911,8 +914,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
         float* yp = ybase + ((long)(2 * ty) * W + 2 * txr) * a.y_cs;
         float v0 = (keep[r][0] + other.x) * sc + sh, v1 = (keep[r][1] + other.y) * sc + sh;
         if (do_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        if (row_ok && ow_l + 2 * txr < W) yp[0] = v0;
-        if (row_ok && ow_l + 2 * txr + 1 < W) yp[a.y_cs] = v1;
+        const bool ok0 = row_ok && ow_l + 2 * txr < W, ok1 = row_ok && ow_l + 2 * txr + 1 < W;
+        if (ok0) { yp[0] = v0; gs += v0; gss = fmaf(v0, v0, gss); }
+        if (ok1) { yp[a.y_cs] = v1; gs += v1; gss = fmaf(v1, v1, gss); }
+    }
+    // fused GroupNorm statistics of the NEXT layer's normalisation (fcos.py:182-186): fold the lane's 32 outputs over the
+    // channels of its group (adjacent lanes) and the two column halves, one {sum, sumsq} record per (tile, row parity, group)
+    if (a.gn_ws) {
+        for (int o = 1; o < a.gn_cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
+        gs += __shfl_xor(gs, 32);
+        gss += __shfl_xor(gss, 32);
+        if (cvalid && hh == 0 && (li & (a.gn_cpg - 1)) == 0) {
+            double* o = a.gn_ws + (((long)bx * 2 + fh) * a.gn_groups + co / a.gn_cpg) * 2;
+            o[0] = (double)gs;
+            o[1] = (double)gss;
+        }
     }
 }
 
@@ -1097,6 +1113,14 @@ static void fill_problem(ConvProblem& p, const cmk_conv_desc* d) {
     p.total_pix = (long)p.N * p.Ho * p.Wo;
 }
 
+static int setup_gn(ConvArgs& a, const cmk_conv_desc* d) {
+    const int cpg = d->gn_groups > 0 ? d->Cout / d->gn_groups : 0;
+    if (d->relu_upto != 0 || d->gn_groups < 1 || d->Cout % d->gn_groups || cpg > 32 || (cpg & (cpg - 1)))
+        return fail(CMK_EINVAL, "conv: fused GroupNorm statistics need relu_upto == 0 and a power-of-two group width <= 32%s", "");
+    a.gn_ws = d->gn_ws; a.gn_cpg = cpg; a.gn_groups = d->gn_groups;
+    return CMK_OK;
+}
+
 static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const cmk_conv_desc* d = &descs[0];
     ConvArgs a;
@@ -1116,6 +1140,11 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino || (d->in_scale && d->tune_wm != 6))
             return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
         if (d->splitk > 1) return fail(CMK_EINVAL, "conv: split-K is a direct-kernel feature%s", "");
+        if (d->gn_ws) {
+            if (d->tune_wm != 6) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics need the 2-WG Winograd form%s", "");
+            int rc = setup_gn(a, d);
+            if (rc) return rc;
+        }
         a.w = d->w_wino;
         return launch_wino(a, d->tune_wm - 3, st);
     }
@@ -1134,15 +1163,21 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     }
     Variant v;
     if (d->tune_wm || d->tune_sc || d->tune_wn) {      // the caller measured and picked a variant
+        if (d->gn_ws) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics are only produced by the Winograd form (tune_wm 6)%s", "");
         v = Variant{d->tune_wm, d->tune_sc, d->tune_wn};
         if (!variant_ok(taps, d->stride, cout32, v.wm, v.sc, v.wn)) return fail(CMK_EINVAL, "conv: variant not available for this shape%s", "");
     } else {
         // untuned default: the 2-WG/CU Winograd form wins on every 3x3 stride-1 shape measured (tools/bench_wino.py), so take it
         // whenever the caller packed the transformed weights; otherwise the direct-kernel cost model decides
         if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && d->w_wino && d->Cin >= 32 && d->splitk <= 1) {
+            if (d->gn_ws) {
+                int rc = setup_gn(a, d);
+                if (rc) return rc;
+            }
             a.w = d->w_wino;
             return launch_wino(a, 3, st);
         }
+        if (d->gn_ws) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics are only produced by the Winograd form%s", "");
         // stride-2 3x3 on a map of at most 16x16 outputs (maskiou conv4 14->7, P6/P7): the spatial tiles would be mostly empty
         if (d->ksize == 3 && d->stride == 2 && n == 1 && d->res_mode != 2 && !d->in_scale && a.p[0].Ho <= 16 && a.p[0].Wo <= 16) {
             const int cout_pad32 = cout32 <= 7 ? cout32 : cdiv(cout32, 4) * 4;
@@ -1173,6 +1208,8 @@ extern "C" int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize) {
     return taps * nch * cmk_conv_cout_pad(Cout) * 16;
 }
 
+extern "C" int cmk_conv_gn_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 15) / 16); }
+
 extern "C" int64_t cmk_wino_packed_floats(int Cout, int Cin) {
     return (int64_t)((Cin + 15) / 16) * ((Cout + 63) / 64) * 16 * 64 * 16;
 }
@@ -1192,7 +1229,8 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
         if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
-            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || (b->in_scale == nullptr) != (a->in_scale == nullptr))
+            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
+            b->gn_ws != a->gn_ws || b->gn_groups != a->gn_groups || b->splitk > 1)
             return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
     }
     return run(descs, n, stream);

@@ -539,6 +539,71 @@ extern "C" int cmk_groupnorm_affine(const float* x, const float* gamma, const fl
     return check_launch("gn_finalize");
 }
 
+struct GnTileLevels {
+    float* out_scale[GN_MAXL];
+    float* out_shift[GN_MAXL];
+    int HW[GN_MAXL], tile_begin[GN_MAXL], tiles[GN_MAXL];
+};
+// statistics written by the conv epilogue (cmk_conv_desc.gn_ws): records ((tile*2 + parity)*groups + group) x {sum, sumsq}
+__global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const GnTileLevels L, const double* __restrict__ ws, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int N, int C, int groups, float eps) {
+    __shared__ double rs[256], rss[256];
+    __shared__ float s_mean[64], s_rstd[64];
+    const int n = blockIdx.x, l = blockIdx.y;
+    const int parts = 256 / groups;                       // thread = (part, group): consecutive threads read consecutive groups
+    const int g = threadIdx.x % groups, part = threadIdx.x / groups;
+    double a = 0.0, b = 0.0;
+    if (part < parts) {
+        const long r0 = ((long)L.tile_begin[l] + (long)n * L.tiles[l]) * 2;
+        const int nrec = L.tiles[l] * 2;
+        for (int r = part; r < nrec; r += parts) {
+            const double* w = ws + ((r0 + r) * groups + g) * 2;
+            a += w[0];
+            b += w[1];
+        }
+    }
+    rs[threadIdx.x] = a;
+    rss[threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        a = 0.0; b = 0.0;
+        for (int k = 0; k < parts; ++k) { a += rs[k * groups + threadIdx.x]; b += rss[k * groups + threadIdx.x]; }
+        const double cnt = (double)L.HW[l] * (C / groups);
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[threadIdx.x] = (float)mean;
+        s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float sc = s_rstd[c / cpg] * gamma[c];
+        L.out_scale[l][(long)n * C + c] = sc;
+        L.out_shift[l][(long)n * C + c] = beta[c] - s_mean[c / cpg] * sc;
+    }
+}
+
+extern "C" int cmk_groupnorm_affine_tiles(const double* ws, const int* Hs, const int* Ws, int nlev, const float* gamma, const float* beta, int N,
+                                          int C, int groups, float eps, float* const* out_scale, float* const* out_shift, void* stream) {
+    if (!ws || !Hs || !Ws || !gamma || !beta || !out_scale || !out_shift) return fail(CMK_EINVAL, "groupnorm_affine_tiles: null pointer%s", "");
+    if (nlev < 1 || nlev > GN_MAXL || N < 1) return fail(CMK_EINVAL, "groupnorm_affine_tiles: 1..5 levels%s", "");
+    if (groups < 1 || groups > 64 || C % groups || C > 4096) return fail(CMK_EINVAL, "groupnorm_affine_tiles: unsupported C/groups%s", "");
+    GnTileLevels L;
+    int begin = 0;
+    for (int l = 0; l < GN_MAXL; ++l) {
+        const bool ok = l < nlev;
+        if (ok && (!out_scale[l] || !out_shift[l] || Hs[l] < 1 || Ws[l] < 1)) return fail(CMK_EINVAL, "groupnorm_affine_tiles: bad level%s", "");
+        L.out_scale[l] = ok ? out_scale[l] : nullptr; L.out_shift[l] = ok ? out_shift[l] : nullptr;
+        L.HW[l] = ok ? Hs[l] * Ws[l] : 1;
+        L.tiles[l] = ok ? ((Hs[l] + 7) / 8) * ((Ws[l] + 15) / 16) : 0;    // == cmk_conv_gn_tiles
+        L.tile_begin[l] = begin;
+        begin += N * L.tiles[l];
+    }
+    hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(N, nlev), dim3(256), 0, (hipStream_t)stream, L, ws, gamma, beta, N, C, groups, eps);
+    return check_launch("gn_finalize_tiles");
+}
+
 extern "C" int cmk_groupnorm_affine_multi(const float* const* xs, const int* HWs, int nlev, const float* gamma, const float* beta, double* ws,
                                           int ws_chunks, int N, int C, int groups, float eps, float* const* out_scale, float* const* out_shift,
                                           void* stream) {

@@ -110,8 +110,7 @@ class FCOSHead(HipModule):
                 xs = ops.conv_out_multi(xs, [pc] * len(xs), relu=True, in_affine=aff)
                 aff = None
             else:
-                xs = ops.conv_out_multi(xs, [pc] * len(xs), in_affine=aff)
-                aff = ops.groupnorm_affine_multi([x.t for x in xs], gamma, beta, groups, eps)
+                xs, aff = ops.conv_gn_multi(xs, [pc] * len(xs), gamma, beta, groups, eps, in_affine=aff)
         return xs, aff
 
     def forward_views(self, feats: List[View]):

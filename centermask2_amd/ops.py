@@ -305,6 +305,60 @@ def conv2d_multi(xs: Sequence[View], pcs: Sequence[PackedConv], ys: Sequence[Vie
     del ws
 
 
+def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32,
+                  eps: float = 1e-5, in_affine=None):
+    """Tower conv (no activation) over several levels + the statistics of the GroupNorm that follows (fcos.py:182-186).
+    Returns (raw conv outputs, [(scale, shift)] per level) — the affine is applied by the NEXT conv while staging.
+    When the Winograd 2-WG kernel runs the conv, its epilogue produces the statistics (no pass over the output)."""
+    lib = _lib.load()
+    n = len(xs)
+    pc = pcs[0]
+    ys = [View(torch.empty((x.t.shape[0], x.t.shape[1], x.t.shape[2], pc.cout), dtype=torch.float32, device=x.t.device)) for x in xs]
+    descs = (ConvDesc * n)()
+    for i in range(n):
+        assert pcs[i].w.data_ptr() == pc.w.data_ptr()
+        _fill_desc(descs[i], xs[i], pcs[i], ys[i], False, None, None, False, False, in_affine[i] if in_affine is not None else None)
+    key = _problem_key(descs, n)
+    ws = _apply_tuning(descs, n, key)
+
+    def launch():
+        if PROFILE is None:
+            return check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi")
+        taps = pc.k * pc.k
+        flops = sum(2.0 * y.t.shape[0] * y.t.shape[1] * y.t.shape[2] * pc.cin * pc.cout * taps for y in ys)
+        nbytes = sum(4.0 * y.t.shape[0] * y.t.shape[1] * y.t.shape[2] * (pc.cin + pc.cout) for y in ys) + 4.0 * pc.cin * pc.cout * taps
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi")
+        e1.record()
+        PROFILE.append((_kernel_name(taps, 1, _TUNED.get(key)), flops, nbytes, e0, e1, None))
+
+    d0 = descs[0]
+    cpg = pc.cout // groups if groups > 0 and pc.cout % groups == 0 else 0
+    wino = d0.tune_wm == 6 or ((d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0) and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
+    fused = wino and 0 < cpg <= 32 and (cpg & (cpg - 1)) == 0 and all(x.t.shape[0] == xs[0].t.shape[0] for x in xs)
+    if not fused:
+        launch()
+        del ws
+        return ys, groupnorm_affine_multi([y.t for y in ys], gamma, beta, groups, eps)
+    nimg, dev = xs[0].t.shape[0], xs[0].t.device
+    tiles = sum(nimg * lib.cmk_conv_gn_tiles(y.t.shape[1], y.t.shape[2]) for y in ys)
+    gws = torch.empty((tiles, 2, groups, 2), dtype=torch.float64, device=dev)
+    for i in range(n):
+        descs[i].gn_ws, descs[i].gn_groups = gws.data_ptr(), groups
+    launch()
+    out = [(torch.empty((nimg, pc.cout), dtype=torch.float32, device=dev), torch.empty((nimg, pc.cout), dtype=torch.float32, device=dev)) for _ in ys]
+    hs, wss = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+    ps, pb = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+    for i, y in enumerate(ys):
+        hs[i], wss[i] = y.t.shape[1], y.t.shape[2]
+        ps[i], pb[i] = out[i][0].data_ptr(), out[i][1].data_ptr()
+    check(lib.cmk_groupnorm_affine_tiles(gws.data_ptr(), hs, wss, n, gamma.data_ptr(), beta.data_ptr(), nimg, pc.cout, groups, eps, ps, pb,
+                                         _stream()), "cmk_groupnorm_affine_tiles")
+    del ws
+    return ys, out
+
+
 def conv_out_multi(xs: Sequence[View], pcs: Sequence[PackedConv], **kw) -> List[View]:  # kw: relu, relu_upto, in_affine
     ys = [View(torch.empty((x.t.shape[0], x.t.shape[1], x.t.shape[2], pcs[0].cout), dtype=torch.float32, device=x.t.device)) for x in xs]
     conv2d_multi(xs, pcs, ys, **kw)

@@ -68,6 +68,12 @@ typedef struct {
      * floats, caller-owned); a second launch sums them and applies the epilogue.  For skinny GEMMs (maskiou_fc1: 400 x 12544 x 1024,
      * maskiou_head.py:116) whose M x N tiles cannot fill 256 CUs.  0/1 = off. */
     int splitk; float* splitk_ws;
+    /* optional fused GroupNorm STATISTICS of this conv's output (the GroupNorm that follows it, fcos.py:182-186): only with
+     * tune_wm == 6, relu_upto == 0 and Cout/gn_groups a power of two <= 32.  The kernel writes {sum, sum of squares} per
+     * (spatial tile of 8x16 outputs, row parity, group) to gn_ws as doubles: record index ((tile*2 + parity)*gn_groups + group),
+     * tiles numbered image-major per problem (for _multi: problems back to back) with cmk_conv_gn_tiles(H, W) tiles per image;
+     * cmk_groupnorm_affine_tiles turns them into the per-(image, channel) scale/shift.  NULL = off. */
+    double* gn_ws; int gn_groups;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
 /* Same conv applied to up to 5 inputs of different H x W in ONE launch (the FCOS towers/predictors share their weights
@@ -78,6 +84,8 @@ int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* stream);
 int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize);
 int cmk_conv_cout_pad(int Cout);
 int64_t cmk_wino_packed_floats(int Cout, int Cin);
+/* spatial tiles per image of the fused-statistics conv (8 x 16 outputs each) */
+int cmk_conv_gn_tiles(int H, int W);
 
 /* ---- depth-wise 3x3, pad 1, stride 1|2, no bias / norm / activation (vovnet.py:110-119 'dw_conv3x3', the dw half of the
  * depth-wise VoVNet bodies V-19-slim-dw-eSE / V-19-dw-eSE vovnet.py:30-48).  x, y are NHWC channel-slice views
@@ -116,6 +124,10 @@ int cmk_groupnorm_affine(const float* x, const float* gamma, const float* beta, 
 int cmk_groupnorm_affine_multi(const float* const* xs, const int* HWs, int nlev, const float* gamma, const float* beta, double* ws,
                                int ws_chunks, int N, int C, int groups, float eps, float* const* out_scale, float* const* out_shift,
                                void* stream);
+/* Second half of the fused form: the statistics were written by the conv itself (cmk_conv_desc.gn_ws, all levels of one
+ * cmk_conv2d_nhwc[_multi] call, N images each); this turns them into the same per-(image, channel) scale/shift. */
+int cmk_groupnorm_affine_tiles(const double* ws, const int* Hs, const int* Ws, int nlev, const float* gamma, const float* beta,
+                               int N, int C, int groups, float eps, float* const* out_scale, float* const* out_shift, void* stream);
 
 /* ---- FCOS candidate selection + box decode (fcos_outputs.py:396-466) ------------------------------------------ */
 typedef struct {

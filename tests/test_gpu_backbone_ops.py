@@ -295,6 +295,34 @@ def test_conv_fused_groupnorm_relu_input(dev, variant):
     assert _lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
 
 
+@pytest.mark.parametrize("cout,groups", [(256, 32), (64, 32), (96, 3)])
+def test_conv_with_fused_groupnorm_statistics(dev, cout, groups):
+    """The Winograd epilogue's {sum, sumsq} records -> the same per-(image, channel) affine as a pass over the output."""
+    g = torch.Generator().manual_seed(21)
+    shapes = [(2, 20, 36), (2, 9, 17), (2, 5, 3)]
+    cin = 64
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn((cout,), generator=g) * 0.1
+    gamma = (torch.rand((cout,), generator=g) + 0.5).to(dev)
+    beta = (torch.randn((cout,), generator=g) * 0.1).to(dev)
+    pc = ops.PackedConv(wt, None, bias, dev)
+    xs = [torch.randn((n, cin, h, w), generator=g) for n, h, w in shapes]
+    ys, aff = ops.conv_gn_multi([ops.as_view(x.to(dev)) for x in xs], [pc] * 3, gamma, beta, groups, 1e-5)
+    torch.cuda.synchronize()
+    for x, y, (sc, sh) in zip(xs, ys, aff):
+        ref = F.conv2d(x, wt, bias, padding=1)
+        _close(y.nchw(), ref)
+        n, c = ref.shape[:2]
+        r = ref.reshape(n, groups, -1).double()
+        mean, var = r.mean(2), r.var(2, unbiased=False)
+        rstd = (1.0 / torch.sqrt(var + 1e-5)).repeat_interleave(c // groups, 1).float()
+        mean = mean.repeat_interleave(c // groups, 1).float()
+        ref_sc = rstd * gamma.cpu()[None]
+        ref_sh = beta.cpu()[None] - mean * ref_sc
+        _close(sc, ref_sc, 1e-4)
+        _close(sh, ref_sh, 1e-4)
+
+
 def test_groupnorm_affine_multi_level(dev):
     shapes = [(100, 160), (13, 20), (7, 10), (1, 2)]
     gamma = torch.rand(256, generator=torch.Generator().manual_seed(42)) + 0.5
