@@ -24,11 +24,16 @@ struct RoiLevels {
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels L, int C, const float* __restrict__ boxes,
                                                        const int32_t* __restrict__ counts, const float* __restrict__ img_area, int topk,
                                                        int out_size, int sampling_ratio, float* __restrict__ y, int y_cs,
-                                                       int32_t* __restrict__ out_level) {
-    const int r = blockIdx.y;
+                                                       int32_t* __restrict__ out_level, int num_rois) {
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; all bin groups of one RoI go to the same XCD so the
+    // feature rows it samples are fetched into ONE L2 (the adaptive sampling grid re-reads neighbouring pixels many times)
+    const int bpr = (out_size * out_size + 3) >> 2;          // workgroups (4 bins each) per RoI
+    const int xq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int r = (xq / bpr) * 8 + xcd;
+    if (r >= num_rois) return;
     const int n = r / topk, s = r - n * topk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bin = blockIdx.x * 4 + wave;
+    const int bin = (xq % bpr) * 4 + wave;
     if (bin >= out_size * out_size) return;
     const int ph = bin / out_size, pw = bin - ph * out_size;
     float* yo = y + ((long)r * out_size * out_size + bin) * y_cs;
@@ -223,8 +228,8 @@ extern "C" int cmk_roi_align_ratio(const float* const* feats, const int* feat_h,
         L.scale[l] = ok ? scales[l] : 1.f;
     }
     int R = N * topk;
-    hipLaunchKernelGGL(roi_align_kernel, dim3(cdiv(out_size * out_size, 4), R), dim3(256), 0, (hipStream_t)stream, L, C, boxes, counts,
-                       img_area, topk, out_size, sampling_ratio, y, y_cs, out_level);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(cdiv(out_size * out_size, 4) * (((R + 7) / 8) * 8)), dim3(256), 0, (hipStream_t)stream, L, C, boxes,
+                       counts, img_area, topk, out_size, sampling_ratio, y, y_cs, out_level, R);
     return check_launch("roi_align");
 }
 
