@@ -1,6 +1,7 @@
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
+WM = int(sys.argv[1]) if len(sys.argv) > 1 else 6          # 6 = 2-WG form, 4 = 8-wave form
 from centermask2_amd import ops, _lib
 from centermask2_amd.ops import View
 lib = _lib.load()
@@ -13,7 +14,7 @@ for (n, h, w, cin, cout) in [(1,16,16,64,64),(1,16,16,128,64),(1,16,16,256,64),(
     for rep in range(3):
         y = View(torch.full((n, h, w, cout), -5.0, device="cuda"))
         d = (_lib.ConvDesc * 1)(); ops._fill_desc(d[0], xv, pc, y, False, None, None, False, False)
-        d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 6, 16, 2
+        d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = WM, 16, 2
         assert lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) == 0
         torch.cuda.synchronize()
         e = (y.nchw().cpu() - ref).abs()
