@@ -208,11 +208,17 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
             if ((it + 1) * 256 <= G::APIX * 4 || idx < G::APIX * 4) {
                 f32x4 v = a_stage[it];
                 const bool ok = (a_ok >> it) & 1u;
+                // rare, wave-uniform options: real branches (the empty asm keeps hipcc from if-converting them into selects that
+                // every conv would execute — each VALU instruction here costs the matrix pipe ~4 cycles, tools/probe/mfma_probe2)
                 if (has_aff) {
+                    asm volatile("" ::: "memory");
                     v.x = fmaxf(v.x * in_sc.x + in_sh.x, 0.f); v.y = fmaxf(v.y * in_sc.y + in_sh.y, 0.f);
                     v.z = fmaxf(v.z * in_sc.z + in_sh.z, 0.f); v.w = fmaxf(v.w * in_sc.w + in_sh.w, 0.f);
                 }
-                if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (a.in_relu) {
+                    asm volatile("" ::: "memory");
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
                 v.x = ok ? v.x : 0.f;
                 v.y = ok ? v.y : 0.f;
                 v.z = ok ? v.z : 0.f;
