@@ -774,18 +774,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     const int prow0 = uhalf ? 2 : 0, qrow0 = uhalf ? 1 : 2;      // part 0 (ii = 0): sign -1 for both halves
     const int prow1 = 1, qrow1 = uhalf ? 3 : 2;                  // part 1 (ii = 1)
     const float sg1 = uhalf ? -1.0f : 1.0f;
-    auto transform_part = [&](int ii) {
+    // The input transform is split into its 8 LDS reads and the arithmetic + 4 LDS writes, so a step can put all its reads in
+    // flight at the top and do the arithmetic between the MFMAs once the data is certainly there.
+    auto tf_load = [&](int ii, f32x4 (&pv)[4], f32x4 (&qv)[4]) {
         const float* src = sH + ((2 * t_ty) * 18 + 2 * t_tx) * PST + t_q * 4;
         const float* ps = src + (ii == 0 ? prow0 : prow1) * 18 * PST;
         const float* qs = src + (ii == 0 ? qrow0 : qrow1) * 18 * PST;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pv[j] = *reinterpret_cast<const f32x4*>(ps + j * PST);
+            qv[j] = *reinterpret_cast<const f32x4*>(qs + j * PST);
+        }
+    };
+    auto tf_store = [&](int ii, const f32x4 (&pv)[4], const f32x4 (&qv)[4]) {
         const float sg = ii == 0 ? -1.0f : sg1;
         f32x4 x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 pv = *reinterpret_cast<const f32x4*>(ps + j * PST);
-            f32x4 qv = *reinterpret_cast<const f32x4*>(qs + j * PST);
-            x[j] = pv + sg * qv;
-        }
+        for (int j = 0; j < 4; ++j) x[j] = pv[j] + sg * qv[j];
         f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
         float* dst = sV + (((2 * t_half + ii) * 4) * 32 + t_tile) * 16 + v_chunk;
         *reinterpret_cast<f32x4*>(dst + 0 * 32 * 16) = v0;
@@ -793,6 +798,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
         *reinterpret_cast<f32x4*>(dst + 2 * 32 * 16) = v2;
         *reinterpret_cast<f32x4*>(dst + 3 * 32 * 16) = v3;
     };
+    auto transform_part = [&](int ii) {
+        f32x4 pv[4], qv[4];
+        tf_load(ii, pv, qv);
+        tf_store(ii, pv, qv);
+    };
+
+    // epilogue scale/shift are fetched here, long before they are needed: loaded in the epilogue (under the cout mask) the
+    // compiler's waitcnt bookkeeping could not prove them landed at the joins of the masked store blocks and put `s_waitcnt
+    // vmcnt(0)` in front of every one of a lane's 32 global stores, i.e. each store waited for the previous one to retire
+    // (8 of a workgroup's 47 us).
+    const int co = co0 + ng * 32 + li;
+    const bool cvalid = co < a.Cout;
+    const float sc = P.scale[min(co, a.Cout - 1)];
+    const float sh = P.shift[min(co, a.Cout - 1)];
 
     f32x16 acc[8];
 #pragma unroll
@@ -842,6 +861,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
                 b0[fl] = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c0);
                 b1[fl] = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c1);
             }
+            // All LDS reads of the step — the eight operand pieces and, in steps 0 and 2, the eight patch reads of the input transform —
+            // are issued here, before anything else.  Left to itself the scheduler reuses one register pair per (fl, piece) and emits
+            // read-2 / wait / 4 MFMAs / read-2 / wait ..., and it parks the transform's read -> VALU chains between the MFMAs so that
+            // every lgkmcnt wait drains the matrix pipe.
+            f32x4 pv[4], qv[4];
+            if (g == 0) tf_load(1, pv, qv);      // this chunk, rows used from step 2 on
+            if (g == 2) tf_load(0, pv, qv);      // next chunk (clamped), rows last read in step 1
+            __builtin_amdgcn_sched_barrier(0);
             // consecutive MFMAs go to different accumulators (no back-to-back dependent pair)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -853,18 +880,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int fl = 0; fl < 2; ++fl)
                     acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[fl][s], b1[fl][s], acc[g * 2 + fl], 0, 0, 0);
-            if (g == 0) transform_part(1);       // this chunk, rows used from step 2 on
+            if (g == 0) tf_store(1, pv, qv);
             if (g == 1) store_H();               // everyone finished reading the old halo in step 0
-            if (g == 2) transform_part(0);       // next chunk (clamped), rows last read in step 1
-            // interleave: the 8 operand reads first, then per pair of MFMAs a slice of the other work
+            if (g == 2) tf_store(0, pv, qv);
+            // interleave: per pair of MFMAs a slice of the other work, the transform arithmetic starting after the first four MFMAs
             // (masks: VALU 0x2, MFMA 0x8, DS read 0x100, DS write 0x200)
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
             if (g == 0 || g == 2) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 6; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 8 patch reads
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 4 V writes (the surplus groups stay empty)
                 }
             } else if (g == 1) {
@@ -902,10 +928,284 @@ __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
     }
     lds_dma_barrier();
     const int partner = wave ^ 2;
-    const int co = co0 + ng * 32 + li;
+    const bool do_relu = co < a.relu_upto;
+    // accumulator row r of lane half hh is tile (ty, tx) = (r >> 2, (r & 3) + 4*hh): the row offset of a store is uniform per r,
+    // only the 8*hh column shift and the channel are per lane -> one lane base pointer, scalar offsets
+    const int ow_l = ow0 + 8 * hh;
+    float* ybase = P.y + (((long)n * H + oh0 + fh) * W + ow_l) * a.y_cs + a.y_co + co;
+    float gs = 0.f, gss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ty = r >> 2, txr = r & 3;
+        const float2 other = ex[(partner * 16 + r) * 64 + lane];
+        const bool row_ok = cvalid && (oh0 + 2 * ty + fh < H);
+        float* yp = ybase + ((long)(2 * ty) * W + 2 * txr) * a.y_cs;
+        float v0 = (keep[r][0] + other.x) * sc + sh, v1 = (keep[r][1] + other.y) * sc + sh;
+        if (do_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        const bool ok0 = row_ok && ow_l + 2 * txr < W, ok1 = row_ok && ow_l + 2 * txr + 1 < W;
+        if (ok0) { yp[0] = v0; gs += v0; gss = fmaf(v0, v0, gss); }
+        if (ok1) { yp[a.y_cs] = v1; gs += v1; gss = fmaf(v1, v1, gss); }
+    }
+    // fused GroupNorm statistics of the NEXT layer's normalisation (fcos.py:182-186): fold the lane's 32 outputs over the
+    // channels of its group (adjacent lanes) and the two column halves, one {sum, sumsq} record per (tile, row parity, group)
+    if (a.gn_ws) {
+        for (int o = 1; o < a.gn_cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
+        gs += __shfl_xor(gs, 32);
+        gss += __shfl_xor(gss, 32);
+        if (cvalid && hh == 0 && (li & (a.gn_cpg - 1)) == 0) {
+            double* o = a.gn_ws + (((long)bx * 2 + fh) * a.gn_groups + co / a.gn_cpg) * 2;
+            o[0] = (double)gs;
+            o[1] = (double)gss;
+        }
+    }
+}
+
+// Register-weights form of the 2-workgroup kernel (tune_wm 5).  What bounds the LDS-DMA form above is a latency chain, not
+// throughput: a step's weight piece can only be requested one step ahead (two 16 KiB LDS buffers are all that fit next to V and the
+// halo at two workgroups per CU) and an L2 round trip under load is about as long as a step, so every step ends up waiting for it
+// (tools/probe/trace_wino.py).  Here each lane loads its own U operand pieces from global memory into registers TWO steps ahead
+// (three register buffers; layout R = one contiguous KiB per wave load, cmk_conv_desc.w_wino_r), the freed 32 KiB of LDS hold a
+// second V buffer so the input transform of chunk c+1 overlaps the MFMAs of chunk c, and there are two barriers per chunk instead
+// of four, none of which waits for memory.
+constexpr int R_LDS_BYTES = (S_SH + 2 * S_SV) * 4;
+__global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sH = smem;
+    float* sV = smem + S_SH;                 // two V buffers (chunk parity)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, li = lane & 31;
+    const int fh = wave >> 1, ng = wave & 1;
+
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the grid_y workgroups that
+    // share an input tile are given to the SAME XCD, back to back: the tile's halo is fetched into one L2 once.
+    // (b % 8 only says which workgroups share an XCD; nothing here depends on it for correctness.)
+    const int xq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int bx = (xq / a.grid_y) * 8 + xcd, by = xq % a.grid_y;
+    if (bx >= a.total_tiles) return;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
+    const ConvProblem& P = a.p[pi];
+    const int H = P.H, W = P.W;
+    const int tile = bx - P.tile_begin;
+    const int tw = tile % P.tiles_w;
+    const int t2 = tile / P.tiles_w;
+    const int th = t2 % P.tiles_h;
+    const int n = t2 / P.tiles_h;
+    const int oh0 = th * 8, ow0 = tw * 16;
+    const int co0 = by * 64;
+    const int nchunks = a.Cin >> 4;
+
+    const float* xin = P.x + (long)n * H * W * a.x_cs + a.x_co;
+    long g_off[S_H_ITERS];
+    unsigned ok = 0;
+#pragma unroll
+    for (int it = 0; it < S_H_ITERS; ++it) {
+        int idx = it * 256 + tid;
+        int pix = idx >> 2, q = idx & 3;
+        long off = 0;
+        if (idx < S_HALO * 4) {
+            int hr = pix / 18, hc = pix - hr * 18;
+            int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) { off = ((long)ih * W + iw) * a.x_cs + q * 4; ok |= 1u << it; }
+        }
+        g_off[it] = off;
+    }
+    f32x4 h_stage[S_H_ITERS];
+    const bool has_aff = P.in_scale != nullptr;      // fused GroupNorm apply + ReLU of the producer
+    const float* aff_s = has_aff ? P.in_scale + (long)n * a.Cin + (tid & 3) * 4 : nullptr;
+    const float* aff_b = has_aff ? P.in_shift + (long)n * a.Cin + (tid & 3) * 4 : nullptr;
+    f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
+    auto load_H = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < S_H_ITERS; ++it) h_stage[it] = *reinterpret_cast<const f32x4*>(xin + g_off[it] + chunk * 16);
+        if (has_aff) {
+            in_sc = *reinterpret_cast<const f32x4*>(aff_s + chunk * 16);
+            in_sh = *reinterpret_cast<const f32x4*>(aff_b + chunk * 16);
+        }
+    };
+    auto store_H = [&]() {
+#pragma unroll
+        for (int it = 0; it < S_H_ITERS; ++it) {
+            int idx = it * 256 + tid;
+            if ((it + 1) * 256 <= S_HALO * 4 || idx < S_HALO * 4) {
+                f32x4 v = h_stage[it];
+                const bool k = (ok >> it) & 1u;
+                if (has_aff) {
+                    v.x = fmaxf(v.x * in_sc.x + in_sh.x, 0.f); v.y = fmaxf(v.y * in_sc.y + in_sh.y, 0.f);
+                    v.z = fmaxf(v.z * in_sc.z + in_sh.z, 0.f); v.w = fmaxf(v.w * in_sc.w + in_sh.w, 0.f);
+                }
+                v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+                *reinterpret_cast<f32x4*>(sH + (idx >> 2) * PST + (idx & 3) * 4) = v;
+            }
+        }
+    };
+    // Weights: same packed U image as the LDS-DMA form ([chunk][ntile][4 steps][4 freq][64 co][16 ci], 16-byte chunks XOR-swizzled),
+    // but every lane fetches its own two 16-byte operand pieces per frequency straight into registers (L2-resident, shared by
+    // all workgroups): no LDS space, no LDS reads and no DMA drain in front of the barriers.
+    const long u_chunk_stride = (long)a.grid_y * 16 * (64 * 16);
+    const int t_half = tid >> 7, t_tile = (tid >> 2) & 31, t_q = tid & 3;
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    const int v_chunk = (t_q ^ ((t_tile >> 2) & 3)) * 4;
+    // Input transform of one frequency row pair: part 0 -> rows {0, 2} (frequencies 0-3 / 8-11, used by steps 0-1),
+    // part 1 -> rows {1, 3} (frequencies 4-7 / 12-15, used by steps 2-3).  Thread half h2 owns rows {2*h2, 2*h2+1}.
+    // Row ii of a thread half is p + sg*q of two patch rows (B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]):
+    //   half 0: row 0 = d0 - d2, row 1 = d1 + d2;   half 1: row 2 = d2 - d1, row 3 = d1 - d3.
+    // The half is wave-uniform, so (p row, q row, sign) are scalars: 8 loads + 16 FMAs per part, no select of two variants.
+    const int uhalf = __builtin_amdgcn_readfirstlane(t_half);
+    const int prow0 = uhalf ? 2 : 0, qrow0 = uhalf ? 1 : 2;      // part 0 (ii = 0): sign -1 for both halves
+    const int prow1 = 1, qrow1 = uhalf ? 3 : 2;                  // part 1 (ii = 1)
+    const float sg1 = uhalf ? -1.0f : 1.0f;
+    auto transform_part = [&](int ii, int buf) {
+        const float* src = sH + ((2 * t_ty) * 18 + 2 * t_tx) * PST + t_q * 4;
+        const float* ps = src + (ii == 0 ? prow0 : prow1) * 18 * PST;
+        const float* qs = src + (ii == 0 ? qrow0 : qrow1) * 18 * PST;
+        const float sg = ii == 0 ? -1.0f : sg1;
+        f32x4 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 pv = *reinterpret_cast<const f32x4*>(ps + j * PST);
+            f32x4 qv = *reinterpret_cast<const f32x4*>(qs + j * PST);
+            x[j] = pv + sg * qv;
+        }
+        f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
+        float* dst = sV + buf * S_SV + (((2 * t_half + ii) * 4) * 32 + t_tile) * 16 + v_chunk;
+        *reinterpret_cast<f32x4*>(dst + 0 * 32 * 16) = v0;
+        *reinterpret_cast<f32x4*>(dst + 1 * 32 * 16) = v1;
+        *reinterpret_cast<f32x4*>(dst + 2 * 32 * 16) = v2;
+        *reinterpret_cast<f32x4*>(dst + 3 * 32 * 16) = v3;
+    };
+
+    const int co = co0 + ng * 32 + li;       // epilogue scale/shift fetched early (see conv_wino4s_kernel)
     const bool cvalid = co < a.Cout;
-    const float sc = cvalid ? P.scale[co] : 0.f;
-    const float sh = cvalid ? P.shift[co] : 0.f;
+    const float sc = P.scale[min(co, a.Cout - 1)];
+    const float sh = P.shift[min(co, a.Cout - 1)];
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    const int c0 = ((2 * hh) ^ sw) * 4, c1 = ((2 * hh + 1) ^ sw) * 4;
+    const float* Abase = sV + ((fh * 8) * 32 + li) * 16;
+    // register-weight layout R: [chunk][ntile][step 4][fh 2][ng 2][fl 2][piece 2][lane 64][4 floats] — every operand load of a wave is
+    // one contiguous KiB (lane = 32*hh + li holds channels 8*hh + 4*piece .. +3 of cout ng*32 + li)
+    const float* u_lane = a.w + (long)by * 16 * (64 * 16) + (fh * 2 + ng) * 1024 + lane * 4;
+    f32x4 bq[3][2][2];                       // [register buffer: step % 3][fl][operand piece]
+    auto load_B = [&](int step, int buf) {   // step = chunk*4 + group: frequencies {2g, 2g+1} of this wave's half
+        const float* s = u_lane + (step >> 2) * u_chunk_stride + (step & 3) * (4 * 64 * 16);
+#pragma unroll
+        for (int fl = 0; fl < 2; ++fl) {
+            bq[buf][fl][0] = *reinterpret_cast<const f32x4*>(s + (fl * 2 + 0) * 256);
+            bq[buf][fl][1] = *reinterpret_cast<const f32x4*>(s + (fl * 2 + 1) * 256);
+        }
+    };
+
+    // Schedule: TWO barriers per chunk, 32 MFMAs per wave between them, nothing but LDS visibility is waited for at a barrier.
+    //   steps 0-1 of chunk c: MFMAs on V(c) (buffer c&1) + the input transform of chunk c+1 from the halo into the other V buffer
+    //   barrier (everyone is done reading the halo)
+    //   steps 2-3: MFMAs + the halo of chunk c+2 registers -> LDS (its global loads were issued in step 0)
+    //   barrier (V(c+1) and the new halo are visible; V(c) may be overwritten)
+    // The weight operands of step s+1 are loaded into the other register buffer while step s runs.
+    const int total_steps = nchunks * 4;
+    load_H(0);
+    store_H();
+    __syncthreads();
+    transform_part(0, 0);
+    transform_part(1, 0);
+    load_H(min(1, nchunks - 1));
+    load_B(0, 0);
+    load_B(min(1, total_steps - 1), 1);
+    __syncthreads();
+    store_H();
+    // weight operands are fetched TWO steps ahead (three register buffers, index = step % 3): the chunk loop is unrolled by three
+    // so that the buffer index is a compile-time constant (12 steps = 0 mod 3)
+    for (int c3 = 0; c3 < nchunks; c3 += 3) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const int c = c3 + cc;
+            if (c >= nchunks) break;
+            const int cnn = min(c + 2, nchunks - 1);
+            const float* A = Abase + (c & 1) * S_SV;
+            const int nbuf = (c + 1) & 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int step = c * 4 + g;
+                constexpr int dummy = 0; (void)dummy;
+                const int sb = (cc * 4 + g) % 3, sb2 = (cc * 4 + g + 2) % 3;
+                if (g == 0 || g == 2) __syncthreads();
+                if (g == 0) load_H(cnn);
+                load_B(min(step + 2, total_steps - 1), sb2);
+                f32x4 a0[2], a1[2];
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl) {
+                    const int al = g * 2 + fl;
+                    a0[fl] = *reinterpret_cast<const f32x4*>(A + al * 32 * 16 + c0);
+                    a1[fl] = *reinterpret_cast<const f32x4*>(A + al * 32 * 16 + c1);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int fl = 0; fl < 2; ++fl)
+                        acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[fl][s], bq[sb][fl][0][s], acc[g * 2 + fl], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int fl = 0; fl < 2; ++fl)
+                        acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[fl][s], bq[sb][fl][1][s], acc[g * 2 + fl], 0, 0, 0);
+                if (g == 0) transform_part(0, nbuf);
+                if (g == 1) transform_part(1, nbuf);
+                if (g == 2) store_H();
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                if (g == 0 || g == 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                } else if (g == 2) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    __syncthreads();
+    float2* ex = reinterpret_cast<float2*>(sV);     // [wave 4][r 16][64 lanes] x (dx 0,1) = 32 KiB
+    float keep[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s0[2], s1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r], m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
+            s0[i] = m0 + m1 + m2;
+            s1[i] = m1 - m2 - m3;
+        }
+        float2 send;
+        if (fh == 0) {
+            keep[r][0] = s0[0] + s0[1]; keep[r][1] = s1[0] + s1[1];
+            send = make_float2(s0[1], s1[1]);
+        } else {
+            keep[r][0] = -s0[0] - s0[1]; keep[r][1] = -s1[0] - s1[1];
+            send = make_float2(s0[0], s1[0]);
+        }
+        ex[(wave * 16 + r) * 64 + lane] = send;
+    }
+    __syncthreads();
+    const int partner = wave ^ 2;
     const bool do_relu = co < a.relu_upto;
     // accumulator row r of lane half hh is tile (ty, tx) = (r >> 2, (r & 3) + 4*hh): the row offset of a store is uniform per r,
     // only the 8*hh column shift and the channel are per lane -> one lane base pointer, scalar offsets
@@ -944,6 +1244,8 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
         if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -951,7 +1253,7 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     for (int i = 0; i < a.nprob; ++i) {
         ConvProblem& p = a.p[i];
         p.tile_begin = blocks;
-        p.tiles_h = cdiv(p.Ho, waves8 == 3 ? 8 : 16);
+        p.tiles_h = cdiv(p.Ho, waves8 >= 2 ? 8 : 16);
         p.tiles_w = cdiv(p.Wo, 16);
         blocks += p.N * p.tiles_h * p.tiles_w;
     }
@@ -959,6 +1261,8 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     a.total_tiles = blocks;
     if (waves8 == 3)
         hipLaunchKernelGGL(conv_wino4s_kernel, dim3(((blocks + 7) / 8) * 8 * a.grid_y), dim3(256), S_LDS_BYTES, st, a);
+    else if (waves8 == 2)
+        hipLaunchKernelGGL(conv_wino4r_kernel, dim3(((blocks + 7) / 8) * 8 * a.grid_y), dim3(256), R_LDS_BYTES, st, a);
     else
         hipLaunchKernelGGL(conv_wino8_kernel, dim3(blocks * a.grid_y), dim3(512), W_LDS_BYTES, st, a);
     return check_launch("conv_wino");
@@ -1142,16 +1446,17 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const int cout32 = (d->Cout + 31) / 32;
     const int taps = d->ksize * d->ksize;
     hipStream_t st = (hipStream_t)stream;
-    if (d->tune_wm == 4 || d->tune_wm == 6) {          // Winograd F(2x2,3x3) (4 = 8 waves / 1 workgroup per CU, 6 = 4 waves x 2 workgroups per CU): 3x3 stride 1, no residual / input ReLU
-        if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino || (d->in_scale && d->tune_wm != 6))
+    if (d->tune_wm == 4 || d->tune_wm == 5 || d->tune_wm == 6) {          // Winograd F(2x2,3x3) (4 = 8 waves / 1 workgroup per CU, 6 = 4 waves x 2 workgroups per CU): 3x3 stride 1, no residual / input ReLU
+        const float* wu = d->tune_wm == 5 ? d->w_wino_r : d->w_wino;
+        if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !wu || (d->in_scale && d->tune_wm == 4))
             return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
         if (d->splitk > 1) return fail(CMK_EINVAL, "conv: split-K is a direct-kernel feature%s", "");
         if (d->gn_ws) {
-            if (d->tune_wm != 6) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics need the 2-WG Winograd form%s", "");
+            if (d->tune_wm == 4) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics need a 2-WG Winograd form%s", "");
             int rc = setup_gn(a, d);
             if (rc) return rc;
         }
-        a.w = d->w_wino;
+        a.w = wu;
         return launch_wino(a, d->tune_wm - 3, st);
     }
     a.ksplit = d->splitk > 1 ? d->splitk : 1;
@@ -1175,13 +1480,13 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     } else {
         // untuned default: the 2-WG/CU Winograd form wins on every 3x3 stride-1 shape measured (tools/bench_wino.py), so take it
         // whenever the caller packed the transformed weights; otherwise the direct-kernel cost model decides
-        if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && d->w_wino && d->Cin >= 32 && d->splitk <= 1) {
+        if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && (d->w_wino || d->w_wino_r) && d->Cin >= 32 && d->splitk <= 1) {
             if (d->gn_ws) {
                 int rc = setup_gn(a, d);
                 if (rc) return rc;
             }
-            a.w = d->w_wino;
-            return launch_wino(a, 3, st);
+            a.w = d->w_wino_r ? d->w_wino_r : d->w_wino;
+            return launch_wino(a, d->w_wino_r ? 2 : 3, st);
         }
         if (d->gn_ws) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics are only produced by the Winograd form%s", "");
         // stride-2 3x3 on a map of at most 16x16 outputs (maskiou conv4 14->7, P6/P7): the spatial tiles would be mostly empty
@@ -1235,7 +1540,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
         if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
-            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
+            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || b->w_wino_r != a->w_wino_r || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
             b->gn_ws != a->gn_ws || b->gn_groups != a->gn_groups || b->splitk > 1)
             return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
     }

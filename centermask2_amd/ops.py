@@ -78,10 +78,8 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 _WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
 
 
-def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
-    """(Cout,Cin,3,3) -> U = G g G^T packed [Cin/16][ceil(Cout/64)][16 freq][64 co][16 ci] for conv_wino_kernel
-    (transform in float64, rounded once to float32)."""
-    lib = _lib.load()
+def _wino_u(w: torch.Tensor) -> torch.Tensor:
+    """(Cout,Cin,3,3) -> U = G g G^T as [chunk][ntile][16 freq in step order][64 co][16 ci] (float64 transform, rounded once)."""
     cout, cin = w.shape[0], w.shape[1]
     u = torch.einsum("ik,ockl,jl->ocij", _WINO_G, w.detach().double().cpu(), _WINO_G).reshape(cout, cin, 16)
     cin_pad, nt = (cin + 15) // 16 * 16, (cout + 63) // 64
@@ -89,15 +87,32 @@ def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
     up[:cin, :cout] = u.permute(1, 0, 2)
     order = [f for g in range(4) for f in (2 * g, 2 * g + 1, 8 + 2 * g, 9 + 2 * g)]      # the kernels' streaming order
     up = up[:, :, order]
-    up = up.reshape(cin_pad // 16, 16, nt, 64, 16).permute(0, 2, 4, 3, 1).contiguous().float()      # [chunk][ntile][freq][co][16 ci]
+    return up.reshape(cin_pad // 16, 16, nt, 64, 16).permute(0, 2, 4, 3, 1).contiguous().float()
+
+
+def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
+    """Packed U for the LDS-DMA Winograd kernels (cmk_conv_desc.w_wino): [Cin/16][ceil(Cout/64)][16 freq][64 co][16 ci]."""
+    lib = _lib.load()
+    up = _wino_u(w)
+    nc, nt = up.shape[0], up.shape[1]
     # the HBM image is the LDS image: 16-byte chunk p of row co holds logical chunk p ^ ((co >> 2) & 3)  (bank-conflict-free
     # ds_read_b128 without padding; global_load_lds copies it verbatim)
     co = torch.arange(64)
     src_chunk = torch.arange(4)[None, :] ^ ((co[:, None] >> 2) & 3)                                      # [co][p] -> logical chunk
-    up = up.reshape(cin_pad // 16, nt, 16, 64, 4, 4)
-    up = torch.gather(up, 4, src_chunk[None, None, None, :, :, None].expand(cin_pad // 16, nt, 16, 64, 4, 4)).reshape(cin_pad // 16, nt, 16, 64, 16).contiguous()
-    assert up.numel() == lib.cmk_wino_packed_floats(cout, cin)
+    up = up.reshape(nc, nt, 16, 64, 4, 4)
+    up = torch.gather(up, 4, src_chunk[None, None, None, :, :, None].expand(nc, nt, 16, 64, 4, 4)).reshape(nc, nt, 16, 64, 16).contiguous()
+    assert up.numel() == lib.cmk_wino_packed_floats(w.shape[0], w.shape[1])
     return up
+
+
+def pack_wino_weight_r(w: torch.Tensor) -> torch.Tensor:
+    """Packed U for the register-weights Winograd kernel (cmk_conv_desc.w_wino_r):
+    [chunk][ntile][step 4][fh 2][ng 2][fl 2][piece 2][lane = 32*hh + li][4] with freq = step*4 + fh*2 + fl (step order),
+    co = ng*32 + li, ci = 8*hh + 4*piece + j — every operand load of a wave is one contiguous KiB."""
+    up = _wino_u(w)
+    nc, nt = up.shape[0], up.shape[1]
+    r = up.reshape(nc, nt, 4, 2, 2, 2, 32, 2, 2, 4)               # [chunk][nt][g][fh][fl][ng][li][hh][piece][j]
+    return r.permute(0, 1, 2, 3, 5, 4, 8, 7, 6, 9).contiguous().reshape(nc, nt, 16, 64, 16)
 
 
 class PackedConv:
@@ -111,7 +126,9 @@ class PackedConv:
         self.cin_pad = (self.cin + 15) // 16 * 16
         self.stride = stride
         self.w = pack_conv_weight(weight).to(device)
-        self.w_wino = pack_wino_weight(weight).to(device) if (self.k == 3 and stride == 1 and self.cin >= 16) else None
+        wino = self.k == 3 and stride == 1 and self.cin >= 16
+        self.w_wino = pack_wino_weight(weight).to(device) if wino else None
+        self.w_wino_r = pack_wino_weight_r(weight).to(device) if wino else None
         self.scale = (torch.ones(self.cout) if scale is None else scale.detach().float().cpu()).contiguous().to(device)
         self.shift = (torch.zeros(self.cout) if shift is None else shift.detach().float().cpu()).contiguous().to(device)
 
@@ -129,6 +146,7 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
     d.x, d.x_cs, d.x_co = x.t.data_ptr(), x.cs, x.co
     d.w = pc.w.data_ptr()
     d.w_wino = pc.w_wino.data_ptr() if getattr(pc, "w_wino", None) is not None else None
+    d.w_wino_r = pc.w_wino_r.data_ptr() if getattr(pc, "w_wino_r", None) is not None else None
     d.scale, d.shift = pc.scale.data_ptr(), pc.shift.data_ptr()
     if res is not None:
         d.res, d.res_cs, d.res_co = res.t.data_ptr(), res.cs, res.co
@@ -235,7 +253,7 @@ def _tune(descs, n, key) -> None:
     if small and d0.ksize == 3:
         cands += [(7, 32, wn, sk) for wn in (1, 2, 4) for sk in sks]      # gather form
     if ALLOW_WINOGRAD:
-        cands += [(4, 16, 2, 1), (6, 16, 2, 1)]   # fused Winograd F(2x2,3x3): 8-wave / 1 WG per CU and 4-wave / 2 WG per CU forms
+        cands += [(4, 16, 2, 1), (5, 16, 2, 1), (6, 16, 2, 1)]   # fused Winograd F(2x2,3x3): 8-wave, register-weights 2-WG, LDS-DMA 2-WG forms
     for tv in cands:
         ws = _set_variant(descs, n, tv)
         if run() != 0:
@@ -335,7 +353,7 @@ def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Te
 
     d0 = descs[0]
     cpg = pc.cout // groups if groups > 0 and pc.cout % groups == 0 else 0
-    wino = d0.tune_wm == 6 or ((d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0) and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
+    wino = d0.tune_wm in (5, 6) or ((d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0) and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
     fused = wino and 0 < cpg <= 32 and (cpg & (cpg - 1)) == 0 and all(x.t.shape[0] == xs[0].t.shape[0] for x in xs)
     if not fused:
         launch()
@@ -635,8 +653,8 @@ def _kernel_name(taps, stride, tv) -> str:
     """The template instantiation rocprofv3 will report: conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>."""
     if not tv or tuple(tv[:3]) == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
-    if tv[0] in (4, 6):
-        return "cmk::conv_wino{}_kernel".format({4: "8", 6: "4s"}[tv[0]])
+    if tv[0] in (4, 5, 6):
+        return "cmk::conv_wino{}_kernel".format({4: "8", 5: "4r", 6: "4s"}[tv[0]])
     wm, sc, wn = tv[:3]
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)

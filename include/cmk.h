@@ -52,13 +52,18 @@ typedef struct {
      * 9 taps x Cin/16 chunks, each A row gathered per tap — for maps too small to fill the spatial tiles (the 14->7 maskiou conv
      * maskiou_head.py:84, P6/P7 fpn.py:32-35); same K order, so again bitwise identical to the tiled variants. */
     int tune_wm; int tune_sc; int tune_wn;
-    /* tune_wm == 6 (4 waves, two workgroups per CU; the default for 3x3 stride 1) or 4 (8 waves, one workgroup per CU) selects the
+    /* tune_wm == 6 (4 waves, two workgroups per CU, weights by LDS-DMA) or 4 (8 waves, one workgroup per CU) selects the
      * fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual): same fp32 arithmetic on the
      * matrix pipe with 2.25x fewer multiplies; results differ from the direct kernel by fp32 rounding only.  It needs the
      * weights pre-transformed to U = G g G^T, packed [Cin/16][ceil(Cout/64)][16 freq in step order][64][16] (cmk_wino_packed_floats);
      * step g streams the frequencies {2g, 2g+1, 8+2g, 9+2g} of the row-major 4x4 frequency grid; within a 64-byte row
      * (one co, 16 ci) the 16-byte chunk at position p holds logical chunk p ^ ((co >> 2) & 3) (the LDS swizzle). */
     const float* w_wino;
+    /* tune_wm == 5 selects the register-weights form of that kernel (weights fetched two steps ahead into registers, double-buffered
+     * transform; the default when w_wino_r is given).  Same U values, packed [Cin/16][ceil(Cout/64)][step 4][fh 2][ng 2][fl 2][piece 2]
+     * [lane 64][4 floats]: frequency = the step-ordered index step*4 + fh*2 + fl of the list above, output channel = ntile*64 + ng*32 +
+     * (lane & 31), input channel = chunk*16 + 8*(lane >> 5) + 4*piece + j.  Same size as w_wino (cmk_wino_packed_floats). */
+    const float* w_wino_r;
     /* optional fused GroupNorm+ReLU of the PRODUCER (fcos.py:182-186): per (image, input channel) x' = relu(x*in_scale + in_shift)
      * is applied while the input tile is staged, so the normalised tensor is never written; arrays of N*Cin floats from
      * cmk_groupnorm_affine.  Supported by the direct kernels and Winograd form 6. */
