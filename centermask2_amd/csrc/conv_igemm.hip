@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
     // register-weight layout R: [chunk][ntile][step 4][fh 2][ng 2][fl 2][piece 2][lane 64][4 floats] — every operand load of a wave is
     // one contiguous KiB (lane = 32*hh + li holds channels 8*hh + 4*piece .. +3 of cout ng*32 + li)
     const float* u_lane = a.w + (long)by * 16 * (64 * 16) + (fh * 2 + ng) * 1024 + lane * 4;
-    f32x4 bq[3][2][2];                       // [register buffer: step % 3][fl][operand piece]
+    f32x4 bq[4][2][2];                       // [register buffer: step % 4][fl][operand piece]
     auto load_B = [&](int step, int buf) {   // step = chunk*4 + group: frequencies {2g, 2g+1} of this wave's half
         const float* s = u_lane + (step >> 2) * u_chunk_stride + (step & 3) * (4 * 64 * 16);
 #pragma unroll
@@ -1106,12 +1106,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
         }
     };
 
-    // Schedule: TWO barriers per chunk, 32 MFMAs per wave between them, nothing but LDS visibility is waited for at a barrier.
+    // Schedule: TWO barriers per chunk, 32 MFMAs per wave between them; no barrier waits for a weight load.
     //   steps 0-1 of chunk c: MFMAs on V(c) (buffer c&1) + the input transform of chunk c+1 from the halo into the other V buffer
     //   barrier (everyone is done reading the halo)
     //   steps 2-3: MFMAs + the halo of chunk c+2 registers -> LDS (its global loads were issued in step 0)
     //   barrier (V(c+1) and the new halo are visible; V(c) may be overwritten)
-    // The weight operands of step s+1 are loaded into the other register buffer while step s runs.
     const int total_steps = nchunks * 4;
     load_H(0);
     store_H();
@@ -1119,64 +1118,59 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
     transform_part(0, 0);
     transform_part(1, 0);
     load_H(min(1, nchunks - 1));
-    load_B(0, 0);
-    load_B(min(1, total_steps - 1), 1);
     __syncthreads();
     store_H();
-    // weight operands are fetched TWO steps ahead (three register buffers, index = step % 3): the chunk loop is unrolled by three
-    // so that the buffer index is a compile-time constant (12 steps = 0 mod 3)
-    for (int c3 = 0; c3 < nchunks; c3 += 3) {
+    // weight operands are fetched two steps ahead into four register buffers (index = step % 4 = g; a buffer is live for two
+    // steps, so three are held at a time)
+    constexpr int PF = 2;
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            const int c = c3 + cc;
-            if (c >= nchunks) break;
-            const int cnn = min(c + 2, nchunks - 1);
-            const float* A = Abase + (c & 1) * S_SV;
-            const int nbuf = (c + 1) & 1;
+    for (int t = 0; t < PF; ++t) load_B(min(t, total_steps - 1), t);
+    for (int c = 0; c < nchunks; ++c) {
+        const int cnn = min(c + 2, nchunks - 1);
+        const float* A = Abase + (c & 1) * S_SV;
+        const int nbuf = (c + 1) & 1;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int step = c * 4 + g;
-                constexpr int dummy = 0; (void)dummy;
-                const int sb = (cc * 4 + g) % 3, sb2 = (cc * 4 + g + 2) % 3;
-                if (g == 0 || g == 2) __syncthreads();
-                if (g == 0) load_H(cnn);
-                load_B(min(step + 2, total_steps - 1), sb2);
-                f32x4 a0[2], a1[2];
+        for (int g = 0; g < 4; ++g) {
+            const int step = c * 4 + g;
+            const int sb = g, sb2 = (g + PF) & 3;
+            if (g == 0 || g == 2) __syncthreads();
+            if (g == 0) load_H(cnn);
+            load_B(min(step + PF, total_steps - 1), sb2);
+            f32x4 a0[2], a1[2];
 #pragma unroll
-                for (int fl = 0; fl < 2; ++fl) {
-                    const int al = g * 2 + fl;
-                    a0[fl] = *reinterpret_cast<const f32x4*>(A + al * 32 * 16 + c0);
-                    a1[fl] = *reinterpret_cast<const f32x4*>(A + al * 32 * 16 + c1);
+            for (int fl = 0; fl < 2; ++fl) {
+                const int al = g * 2 + fl;
+                a0[fl] = *reinterpret_cast<const f32x4*>(A + al * 32 * 16 + c0);
+                a1[fl] = *reinterpret_cast<const f32x4*>(A + al * 32 * 16 + c1);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl)
+                    acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[fl][s], bq[sb][fl][0][s], acc[g * 2 + fl], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl)
+                    acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[fl][s], bq[sb][fl][1][s], acc[g * 2 + fl], 0, 0, 0);
+            if (g == 0) transform_part(0, nbuf);
+            if (g == 1) transform_part(1, nbuf);
+            if (g == 2) store_H();
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            if (g == 0 || g == 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
+            } else if (g == 2) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int fl = 0; fl < 2; ++fl)
-                        acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[fl][s], bq[sb][fl][0][s], acc[g * 2 + fl], 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int fl = 0; fl < 2; ++fl)
-                        acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[fl][s], bq[sb][fl][1][s], acc[g * 2 + fl], 0, 0, 0);
-                if (g == 0) transform_part(0, nbuf);
-                if (g == 1) transform_part(1, nbuf);
-                if (g == 2) store_H();
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                if (g == 0 || g == 1) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    }
-                } else if (g == 2) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    }
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
             }
         }
