@@ -23,7 +23,7 @@ class ConvDesc(Structure):
         ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
         ("ksize", c_int), ("stride", c_int), ("relu_upto", c_int), ("in_relu", c_int),
         ("tune_wm", c_int), ("tune_sc", c_int), ("tune_wn", c_int),
-        ("w_wino", c_void_p), ("w_wino_r", c_void_p),
+        ("w_wino", c_void_p),
         ("in_scale", c_void_p), ("in_shift", c_void_p),
         ("splitk", c_int), ("splitk_ws", c_void_p),
         ("gn_ws", c_void_p), ("gn_groups", c_int),

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, (occ_of(WM, WN, STRIDE))) void conv_igemm_kern
     const int li = lane & 31;
 
     // ---- which problem (FPN level) and which tile ------------------------------------------------------------
-    // XCD-aware order (see conv_wino4s_kernel): the grid_y workgroups of one input tile go to one XCD, back to back
+    // XCD-aware order (see conv_wino4r_kernel): the grid_y workgroups of one input tile go to one XCD, back to back
     const int xq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
     const int bx = (xq / a.grid_y) * 8 + xcd, by = xq % a.grid_y;
     if (bx >= a.total_tiles) return;
@@ -432,541 +432,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Winograd F(2x2, 3x3) variant for 3x3 stride-1 convs, fused in one kernel (input transform, 16 frequency GEMMs on the
+// Winograd F(2x2, 3x3) form for 3x3 stride-1 convs, fused in one kernel (input transform, 16 frequency GEMMs on the
 // matrix pipe, output transform all on chip): 2.25x fewer MFMA flops than the direct form, still plain fp32 arithmetic
 // (transform matrices hold only 0, +-1, +-1/2; results differ from the direct kernel by fp32 rounding only).
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A        per 4x4 input patch d -> 2x2 outputs, summed over input channels
-//   workgroup  = 16x16 output pixels (8x8 tiles) x 64 output channels, 4 waves = 2 (tile groups of 32) x 2 (32 couts)
-//   per 16-channel chunk: halo (18x18 px) -> LDS, every thread transforms one (tile, channel quad) into the 16 frequency
-//   planes V[f][tile][ci]; the pre-transformed weights U[f][co][ci] stream through LDS four frequencies at a time;
-//   each wave keeps 16 accumulators of 32x32 (256 registers, one wave per SIMD) — the output transform is then pure
-//   per-lane register arithmetic because a lane holds all 16 frequencies of its (tile, cout) entries.
+//   workgroup = 8x16 output pixels (32 tiles of 2x2) x 64 output channels, 4 waves = 2 frequency halves (fh) x 2 cout halves (ng);
+//   a wave keeps 8 accumulators of 32 tiles x 32 couts (128 VGPRs), so two workgroups (78 KiB of LDS each) live on a CU and one
+//   workgroup's staging / transform / barrier phases hide under the other's MFMAs;
+//   per 16-channel chunk: halo (10x18 px) -> LDS, every thread transforms (tile, channel quad) patches into the 16 frequency planes
+//   V[f][tile][ci] (16-byte chunks XOR-swizzled, conflict-free ds_read_b128 without padding);
+//   a lane of a 32x32 accumulator holds every frequency of its (tile, cout) entries for its half, so the output transform is
+//   per-lane register arithmetic; the two frequency halves swap partial sums through LDS once at the end.
+// Weights: what bounded the earlier LDS-DMA forms was a latency chain, not throughput — a weight piece could only be requested one
+// step ahead (two 16 KiB LDS buffers were all that fit) and an L2 round trip under load is about as long as a step, so every step
+// waited for it (tools/probe/trace_wino.py, mfma_probe3).  Here each lane loads its own U operand pieces from global memory
+// (L2-resident, shared by all workgroups) into registers TWO steps ahead (layout R = one contiguous KiB per wave load,
+// cmk_conv_desc.w_wino); the LDS that a weight buffer would take holds a second V buffer, so the input transform of chunk c+1
+// overlaps the MFMAs of chunk c with two barriers per chunk, none of which waits for memory.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int W_HALO = 18 * 18;
-constexpr int W_SH = W_HALO * PST;            // floats
-constexpr int W_SV = 16 * 64 * PST;
-constexpr int W_SU = 4 * 64 * PST;            // one group of 4 frequencies
-constexpr int W_LDS_BYTES = (W_SH + W_SV + 2 * W_SU) * 4;
-
-// 8-wave form of the Winograd kernel: same workgroup tile and LDS image, but two waves per SIMD, each owning 8 of the 16
-// frequency accumulators of its (32 tiles x 32 couts) sub-tile (fh = frequency half = rows {0,1} or {2,3} of the 4x4
-// frequency grid).  A wave's barrier / LDS-read / staging stalls now hide under its SIMD partner's MFMAs.  The two halves
-// exchange their partial output transforms through LDS once at the end; each half then stores one of the two output rows.
-__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sH = smem;
-    float* sV = smem + W_SH;
-    float* sU = smem + W_SH + W_SV;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int hh = lane >> 5, li = lane & 31;
-    const int fh = wave >> 2, mg = (wave >> 1) & 1, ng = wave & 1;
-
-    const int bx = blockIdx.x / a.grid_y, by = blockIdx.x - bx * a.grid_y;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < MAXP; ++i)
-        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
-    const ConvProblem& P = a.p[pi];
-    const int H = P.H, W = P.W;
-    const int tile = bx - P.tile_begin;
-    const int tw = tile % P.tiles_w;
-    const int t2 = tile / P.tiles_w;
-    const int th = t2 % P.tiles_h;
-    const int n = t2 / P.tiles_h;
-    const int oh0 = th * 16, ow0 = tw * 16;
-    const int co0 = by * 64;
-    const int nchunks = a.Cin >> 4;
-
-    constexpr int H_ITERS = (W_HALO * 4 + 511) / 512;
-    const float* xin = P.x + (long)n * H * W * a.x_cs + a.x_co;
-    long g_off[H_ITERS];
-    unsigned ok = 0;
-#pragma unroll
-    for (int it = 0; it < H_ITERS; ++it) {
-        int idx = it * 512 + tid;
-        int pix = idx >> 2, q = idx & 3;
-        long off = 0;
-        if (idx < W_HALO * 4) {
-            int hr = pix / 18, hc = pix - hr * 18;
-            int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
-            if (ih >= 0 && ih < H && iw >= 0 && iw < W) { off = ((long)ih * W + iw) * a.x_cs + q * 4; ok |= 1u << it; }
-        }
-        g_off[it] = off;
-    }
-    f32x4 h_stage[H_ITERS];
-    f32x4 u_stage[2];
-    auto load_H = [&](int chunk) {
-#pragma unroll
-        for (int it = 0; it < H_ITERS; ++it) h_stage[it] = *reinterpret_cast<const f32x4*>(xin + g_off[it] + chunk * 16);
-    };
-    auto store_H = [&]() {
-#pragma unroll
-        for (int it = 0; it < H_ITERS; ++it) {
-            int idx = it * 512 + tid;
-            if ((it + 1) * 512 <= W_HALO * 4 || idx < W_HALO * 4) {
-                f32x4 v = h_stage[it];
-                const bool k = (ok >> it) & 1u;
-                v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
-                *reinterpret_cast<f32x4*>(sH + (idx >> 2) * PST + (idx & 3) * 4) = v;
-            }
-        }
-    };
-    auto load_U = [&](int step) {
-        const float* src = a.w + ((long)((step >> 2) * a.grid_y + by) * 16 + (step & 3) * 4) * (64 * 16);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) u_stage[it] = *reinterpret_cast<const f32x4*>(src + (it * 512 + tid) * 4);
-    };
-    auto store_U = [&](int buf) {
-        float* dst = sU + buf * W_SU;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            int idx = it * 512 + tid;
-            int row = idx >> 2;
-            *reinterpret_cast<f32x4*>(dst + row * PST + ((idx & 3) ^ ((row >> 2) & 3)) * 4) = u_stage[it];
-        }
-    };
-    // input transform split over the two thread halves: half h2 produces frequency rows {2*h2, 2*h2+1}
-    const int t_half = tid >> 8, t_tile = (tid >> 2) & 63, t_q = tid & 3;
-    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-    auto transform = [&]() {
-        const float* src = sH + ((2 * t_ty + t_half) * 18 + 2 * t_tx) * PST + t_q * 4;   // patch rows t_half .. t_half+2
-        f32x4 x0[4], x1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 da = *reinterpret_cast<const f32x4*>(src + (0 * 18 + j) * PST);
-            f32x4 db = *reinterpret_cast<const f32x4*>(src + (1 * 18 + j) * PST);
-            f32x4 dc = *reinterpret_cast<const f32x4*>(src + (2 * 18 + j) * PST);
-            if (t_half == 0) { x0[j] = da - dc; x1[j] = db + dc; }        // rows 0,1 of B^T d from d0,d1,d2
-            else             { x0[j] = db - da; x1[j] = da - dc; }        // rows 2,3 of B^T d from d1,d2,d3 (da=d1, db=d2, dc=d3)
-        }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const f32x4* x = ii == 0 ? x0 : x1;
-            f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
-            float* dst = sV + (((2 * t_half + ii) * 4) * 64 + t_tile) * PST + t_q * 4;
-            *reinterpret_cast<f32x4*>(dst + 0 * 64 * PST) = v0;
-            *reinterpret_cast<f32x4*>(dst + 1 * 64 * PST) = v1;
-            *reinterpret_cast<f32x4*>(dst + 2 * 64 * PST) = v2;
-            *reinterpret_cast<f32x4*>(dst + 3 * 64 * PST) = v3;
-        }
-    };
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-
-    const float* Abase = sV + ((fh * 8) * 64 + mg * 32 + li) * PST + hh * 8;
-    const int b_off = ((fh * 2) * 64 + ng * 32 + li) * PST + hh * 8;
-
-    load_H(0);
-    load_U(0);
-    store_H();
-    store_U(0);
-    __syncthreads();
-    transform();
-
-    const int total_steps = nchunks * 4;
-    for (int c = 0; c < nchunks; ++c) {
-        const bool has_next_chunk = (c + 1 < nchunks);
-        if (has_next_chunk) load_H(c + 1);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int step = c * 4 + g;
-            const bool has_next = (step + 1 < total_steps);
-            if (has_next) load_U(step + 1);
-            __syncthreads();
-            const float* B = sU + (g & 1) * W_SU + b_off;
-#pragma unroll
-            for (int fl = 0; fl < 2; ++fl) {
-                const int al = g * 2 + fl;            // local accumulator = frequency fh*8 + al
-                f32x4 a0 = *reinterpret_cast<const f32x4*>(Abase + al * 64 * PST);
-                f32x4 a1 = *reinterpret_cast<const f32x4*>(Abase + al * 64 * PST + 4);
-                f32x4 b0 = *reinterpret_cast<const f32x4*>(B + fl * 64 * PST);
-                f32x4 b1 = *reinterpret_cast<const f32x4*>(B + fl * 64 * PST + 4);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[al], 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[al], 0, 0, 0);
-            }
-            if (has_next) store_U((g + 1) & 1);
-        }
-        if (has_next_chunk) {
-            __syncthreads();
-            store_H();
-            __syncthreads();
-            transform();
-        }
-    }
-
-    // ---- output transform: own half in registers, partner's half through LDS ----------------------------------------------
-    __syncthreads();                       // every wave is done with sV; reuse it for the exchange
-    float* ex = sV;                        // [wave 8][r 16][2][64 lanes]
-    float keep[16][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float s0[2], s1[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {      // my two frequency rows: accumulators i*4 .. i*4+3
-            float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r], m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
-            s0[i] = m0 + m1 + m2;
-            s1[i] = m1 - m2 - m3;
-        }
-        float send0, send1;
-        if (fh == 0) {                     // rows 0,1: Y0 += s[0]+s[1] (kept), Y1 += s[1] (sent)
-            keep[r][0] = s0[0] + s0[1]; keep[r][1] = s1[0] + s1[1];
-            send0 = s0[1]; send1 = s1[1];
-        } else {                           // rows 2,3: Y0 += s[2] (sent), Y1 += -s[2]-s[3] (kept)
-            keep[r][0] = -s0[0] - s0[1]; keep[r][1] = -s1[0] - s1[1];
-            send0 = s0[0]; send1 = s1[0];
-        }
-        ex[((wave * 16 + r) * 2 + 0) * 64 + lane] = send0;
-        ex[((wave * 16 + r) * 2 + 1) * 64 + lane] = send1;
-    }
-    __syncthreads();
-    const int partner = wave ^ 4;
-    const int co = co0 + ng * 32 + li;
-    const bool cvalid = co < a.Cout;
-    const float sc = cvalid ? P.scale[co] : 0.f;
-    const float sh = cvalid ? P.shift[co] : 0.f;
-    const bool do_relu = co < a.relu_upto;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int t = mg * 32 + row;
-        const int oh = oh0 + 2 * (t >> 3) + fh, ow = ow0 + 2 * (t & 7);      // half 0 stores output row 0, half 1 row 1
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            float yv = keep[r][dx] + ex[((partner * 16 + r) * 2 + dx) * 64 + lane];
-            if (cvalid && oh < H && ow + dx < W) {
-                float v = yv * sc + sh;
-                if (do_relu) v = fmaxf(v, 0.f);
-                P.y[(((long)n * H + oh) * W + ow + dx) * a.y_cs + a.y_co + co] = v;
-            }
-        }
-    }
-}
-
-
-typedef __attribute__((address_space(3))) void lds_void;
-
-// Barrier for kernels with global_load_lds in flight.  hipcc does not reliably put the `s_waitcnt vmcnt(0)` in front of a
-// __syncthreads() that guards LDS-DMA data (it was dropped on a rotated loop back-edge here: correct on warm caches, wrong on
-// the first, cold launch), so the drain is written out: every wave retires its own DMA pieces, then the barrier publishes them.
-__device__ __forceinline__ void lds_dma_barrier() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
-// Fourth form, built for residency: a 4-wave workgroup covers 8x16 output pixels (32 tiles) x 64 couts, the two frequency
-// halves and the two cout halves being the four waves.  With V and U kept unpadded (XOR-swizzled 64-byte rows) the LDS
-// image is 78 KiB, so TWO workgroups live on a CU: while one is in its staging/transform phase the other one's MFMAs keep
-// the matrix pipe busy (the measured loss of the 8-wave forms is exactly that phase: all waves of the only resident
-// workgroup transform at the same time and the pipe idles).  Weights arrive by global_load_lds.
 constexpr int S_HALO = 10 * 18;
 constexpr int S_SH = S_HALO * PST;                 // floats
 constexpr int S_SV = 16 * 32 * 16;
-constexpr int S_SU = 4 * 64 * 16;                  // one step = 4 frequencies
-constexpr int S_LDS_BYTES = (S_SH + S_SV + 2 * S_SU) * 4;
 constexpr int S_H_ITERS = (S_HALO * 4 + 255) / 256;
-
-__global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sH = smem;
-    float* sV = smem + S_SH;
-    float* sU = smem + S_SH + S_SV;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int hh = lane >> 5, li = lane & 31;
-    const int fh = wave >> 1, ng = wave & 1;
-
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the grid_y workgroups that
-    // share an input tile are given to the SAME XCD, back to back: the tile's halo is fetched into one L2 once.
-    // (b % 8 only says which workgroups share an XCD; nothing here depends on it for correctness.)
-    const int xq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-    const int bx = (xq / a.grid_y) * 8 + xcd, by = xq % a.grid_y;
-    if (bx >= a.total_tiles) return;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < MAXP; ++i)
-        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
-    const ConvProblem& P = a.p[pi];
-    const int H = P.H, W = P.W;
-    const int tile = bx - P.tile_begin;
-    const int tw = tile % P.tiles_w;
-    const int t2 = tile / P.tiles_w;
-    const int th = t2 % P.tiles_h;
-    const int n = t2 / P.tiles_h;
-    const int oh0 = th * 8, ow0 = tw * 16;
-    const int co0 = by * 64;
-    const int nchunks = a.Cin >> 4;
-
-    const float* xin = P.x + (long)n * H * W * a.x_cs + a.x_co;
-    long g_off[S_H_ITERS];
-    unsigned ok = 0;
-#pragma unroll
-    for (int it = 0; it < S_H_ITERS; ++it) {
-        int idx = it * 256 + tid;
-        int pix = idx >> 2, q = idx & 3;
-        long off = 0;
-        if (idx < S_HALO * 4) {
-            int hr = pix / 18, hc = pix - hr * 18;
-            int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
-            if (ih >= 0 && ih < H && iw >= 0 && iw < W) { off = ((long)ih * W + iw) * a.x_cs + q * 4; ok |= 1u << it; }
-        }
-        g_off[it] = off;
-    }
-    f32x4 h_stage[S_H_ITERS];
-    const bool has_aff = P.in_scale != nullptr;      // fused GroupNorm apply + ReLU of the producer
-    const float* aff_s = has_aff ? P.in_scale + (long)n * a.Cin + (tid & 3) * 4 : nullptr;
-    const float* aff_b = has_aff ? P.in_shift + (long)n * a.Cin + (tid & 3) * 4 : nullptr;
-    f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
-    auto load_H = [&](int chunk) {
-#pragma unroll
-        for (int it = 0; it < S_H_ITERS; ++it) h_stage[it] = *reinterpret_cast<const f32x4*>(xin + g_off[it] + chunk * 16);
-        if (has_aff) {
-            in_sc = *reinterpret_cast<const f32x4*>(aff_s + chunk * 16);
-            in_sh = *reinterpret_cast<const f32x4*>(aff_b + chunk * 16);
-        }
-    };
-    auto store_H = [&]() {
-#pragma unroll
-        for (int it = 0; it < S_H_ITERS; ++it) {
-            int idx = it * 256 + tid;
-            if ((it + 1) * 256 <= S_HALO * 4 || idx < S_HALO * 4) {
-                f32x4 v = h_stage[it];
-                const bool k = (ok >> it) & 1u;
-                if (has_aff) {
-                    v.x = fmaxf(v.x * in_sc.x + in_sh.x, 0.f); v.y = fmaxf(v.y * in_sc.y + in_sh.y, 0.f);
-                    v.z = fmaxf(v.z * in_sc.z + in_sh.z, 0.f); v.w = fmaxf(v.w * in_sc.w + in_sh.w, 0.f);
-                }
-                v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
-                *reinterpret_cast<f32x4*>(sH + (idx >> 2) * PST + (idx & 3) * 4) = v;
-            }
-        }
-    };
-    // LDS-DMA of a step's U image (4 freq x 64 co x 16 ci = 16 KiB, contiguous in HBM and in LDS): each wave copies its own
-    // contiguous 4 KiB with 4 instructions of 1 KiB, so a thread needs ONE 64-bit source address per step (the 4 pieces are
-    // immediate offsets 0/1/2/3 KiB) and the LDS base (M0) is scalar arithmetic on the wave index.
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    const float* u_thread = a.w + (long)by * 16 * (64 * 16) + uwave * 1024 + lane * 4;
-    const long u_chunk_stride = (long)a.grid_y * 16 * (64 * 16);
-    auto glds_U = [&](int step, int buf) {          // step = chunk*4 + group
-        const float* src = u_thread + (step >> 2) * u_chunk_stride + (step & 3) * (4 * 64 * 16);
-        float* dst = sU + buf * S_SU + uwave * 1024;
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            __builtin_amdgcn_global_load_lds(src + it * 256, (lds_void*)(dst + it * 256), 16, 0, 0);
-    };
-    const int t_half = tid >> 7, t_tile = (tid >> 2) & 31, t_q = tid & 3;
-    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-    const int v_chunk = (t_q ^ ((t_tile >> 2) & 3)) * 4;
-    // Input transform of one frequency row pair: part 0 -> rows {0, 2} (frequencies 0-3 / 8-11, used by steps 0-1),
-    // part 1 -> rows {1, 3} (frequencies 4-7 / 12-15, used by steps 2-3).  Thread half h2 owns rows {2*h2, 2*h2+1}.
-    // Row ii of a thread half is p + sg*q of two patch rows (B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]):
-    //   half 0: row 0 = d0 - d2, row 1 = d1 + d2;   half 1: row 2 = d2 - d1, row 3 = d1 - d3.
-    // The half is wave-uniform, so (p row, q row, sign) are scalars: 8 loads + 16 FMAs per part, no select of two variants.
-    const int uhalf = __builtin_amdgcn_readfirstlane(t_half);
-    const int prow0 = uhalf ? 2 : 0, qrow0 = uhalf ? 1 : 2;      // part 0 (ii = 0): sign -1 for both halves
-    const int prow1 = 1, qrow1 = uhalf ? 3 : 2;                  // part 1 (ii = 1)
-    const float sg1 = uhalf ? -1.0f : 1.0f;
-    // The input transform is split into its 8 LDS reads and the arithmetic + 4 LDS writes, so a step can put all its reads in
-    // flight at the top and do the arithmetic between the MFMAs once the data is certainly there.
-    auto tf_load = [&](int ii, f32x4 (&pv)[4], f32x4 (&qv)[4]) {
-        const float* src = sH + ((2 * t_ty) * 18 + 2 * t_tx) * PST + t_q * 4;
-        const float* ps = src + (ii == 0 ? prow0 : prow1) * 18 * PST;
-        const float* qs = src + (ii == 0 ? qrow0 : qrow1) * 18 * PST;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pv[j] = *reinterpret_cast<const f32x4*>(ps + j * PST);
-            qv[j] = *reinterpret_cast<const f32x4*>(qs + j * PST);
-        }
-    };
-    auto tf_store = [&](int ii, const f32x4 (&pv)[4], const f32x4 (&qv)[4]) {
-        const float sg = ii == 0 ? -1.0f : sg1;
-        f32x4 x[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = pv[j] + sg * qv[j];
-        f32x4 v0 = x[0] - x[2], v1 = x[1] + x[2], v2 = x[2] - x[1], v3 = x[1] - x[3];
-        float* dst = sV + (((2 * t_half + ii) * 4) * 32 + t_tile) * 16 + v_chunk;
-        *reinterpret_cast<f32x4*>(dst + 0 * 32 * 16) = v0;
-        *reinterpret_cast<f32x4*>(dst + 1 * 32 * 16) = v1;
-        *reinterpret_cast<f32x4*>(dst + 2 * 32 * 16) = v2;
-        *reinterpret_cast<f32x4*>(dst + 3 * 32 * 16) = v3;
-    };
-    auto transform_part = [&](int ii) {
-        f32x4 pv[4], qv[4];
-        tf_load(ii, pv, qv);
-        tf_store(ii, pv, qv);
-    };
-
-    // epilogue scale/shift are fetched here, long before they are needed: loaded in the epilogue (under the cout mask) the
-    // compiler's waitcnt bookkeeping could not prove them landed at the joins of the masked store blocks and put `s_waitcnt
-    // vmcnt(0)` in front of every one of a lane's 32 global stores, i.e. each store waited for the previous one to retire
-    // (8 of a workgroup's 47 us).
-    const int co = co0 + ng * 32 + li;
-    const bool cvalid = co < a.Cout;
-    const float sc = P.scale[min(co, a.Cout - 1)];
-    const float sh = P.shift[min(co, a.Cout - 1)];
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-
-    const int sw = (li >> 2) & 3;
-    const int c0 = ((2 * hh) ^ sw) * 4, c1 = ((2 * hh + 1) ^ sw) * 4;
-    const float* Abase = sV + ((fh * 8) * 32 + li) * 16;
-    const int b_row = ((fh * 2) * 64 + ng * 32 + li) * 16;
-
-    // Schedule (4 barriers per chunk, no staging phase of its own): everything that is not an MFMA is issued right AFTER a
-    // step's MFMAs, so it executes in their shadow.
-    //   step 0: + second half of THIS chunk's input transform (frequencies 4-7/12-15, first needed in step 2)
-    //   step 1: + halo of the NEXT chunk, registers -> LDS (the loads were issued in step 0)
-    //   step 2: + first half of the NEXT chunk's transform (frequencies 0-3/8-11, last read in step 1)
-    // Frequency rows are renumbered so that steps 0-1 use only "part 0" rows: step g streams {2g,2g+1} of each half, i.e.
-    // local accumulators g*2+fl -> frequency index fh*8 + (g*2+fl); part 0 = local 0-3, part 1 = local 4-7.
-    load_H(0);
-    glds_U(0, 0);
-    store_H();
-    lds_dma_barrier();
-    transform_part(0);
-
-    // Branch-free loop body: "next" indices are clamped to the last chunk/step instead of being guarded (the redundant tail work
-    // reloads data nobody reads), so every step is ONE basic block and the scheduler can interleave the staging / transform
-    // instructions between the MFMAs.  An in-order wave cannot issue anything behind a block of 16 back-to-back MFMAs until the
-    // last one has been accepted by the pipe (~1-2k cycles with the pipe shared by two waves), so without the interleave the
-    // "shadowed" work was in fact serialised behind the MFMA block; the sched_group_barrier sequence below spreads it.
-    const int total_steps = nchunks * 4;
-    for (int c = 0; c < nchunks; ++c) {
-        const int cn = min(c + 1, nchunks - 1);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int step = c * 4 + g;
-            lds_dma_barrier();          // U[g & 1] landed; V rows and halo written in earlier steps are visible; previous step is done
-            glds_U(min(step + 1, total_steps - 1), (g + 1) & 1);
-            if (g == 0) load_H(cn);
-            const float* B = sU + (g & 1) * S_SU + b_row;
-            f32x4 a0[2], a1[2], b0[2], b1[2];
-#pragma unroll
-            for (int fl = 0; fl < 2; ++fl) {
-                const int al = g * 2 + fl;
-                a0[fl] = *reinterpret_cast<const f32x4*>(Abase + al * 32 * 16 + c0);
-                a1[fl] = *reinterpret_cast<const f32x4*>(Abase + al * 32 * 16 + c1);
-                b0[fl] = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c0);
-                b1[fl] = *reinterpret_cast<const f32x4*>(B + fl * 64 * 16 + c1);
-            }
-            // All LDS reads of the step — the eight operand pieces and, in steps 0 and 2, the eight patch reads of the input transform —
-            // are issued here, before anything else.  Left to itself the scheduler reuses one register pair per (fl, piece) and emits
-            // read-2 / wait / 4 MFMAs / read-2 / wait ..., and it parks the transform's read -> VALU chains between the MFMAs so that
-            // every lgkmcnt wait drains the matrix pipe.
-            f32x4 pv[4], qv[4];
-            if (g == 0) tf_load(1, pv, qv);      // this chunk, rows used from step 2 on
-            if (g == 2) tf_load(0, pv, qv);      // next chunk (clamped), rows last read in step 1
-            __builtin_amdgcn_sched_barrier(0);
-            // consecutive MFMAs go to different accumulators (no back-to-back dependent pair)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int fl = 0; fl < 2; ++fl)
-                    acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[fl][s], b0[fl][s], acc[g * 2 + fl], 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int fl = 0; fl < 2; ++fl)
-                    acc[g * 2 + fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[fl][s], b1[fl][s], acc[g * 2 + fl], 0, 0, 0);
-            if (g == 0) tf_store(1, pv, qv);
-            if (g == 1) store_H();               // everyone finished reading the old halo in step 0
-            if (g == 2) tf_store(0, pv, qv);
-            // interleave: per pair of MFMAs a slice of the other work, the transform arithmetic starting after the first four MFMAs
-            // (masks: VALU 0x2, MFMA 0x8, DS read 0x100, DS write 0x200)
-            if (g == 0 || g == 2) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 4 V writes (the surplus groups stay empty)
-                }
-            } else if (g == 1) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 3 halo writes
-                }
-            }
-        }
-    }
-
-    lds_dma_barrier();
-    float2* ex = reinterpret_cast<float2*>(sV);     // [wave 4][r 16][64 lanes] x (dx 0,1) = 32 KiB
-    float keep[16][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float s0[2], s1[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float m0 = acc[i * 4 + 0][r], m1 = acc[i * 4 + 1][r], m2 = acc[i * 4 + 2][r], m3 = acc[i * 4 + 3][r];
-            s0[i] = m0 + m1 + m2;
-            s1[i] = m1 - m2 - m3;
-        }
-        float2 send;
-        if (fh == 0) {
-            keep[r][0] = s0[0] + s0[1]; keep[r][1] = s1[0] + s1[1];
-            send = make_float2(s0[1], s1[1]);
-        } else {
-            keep[r][0] = -s0[0] - s0[1]; keep[r][1] = -s1[0] - s1[1];
-            send = make_float2(s0[0], s1[0]);
-        }
-        ex[(wave * 16 + r) * 64 + lane] = send;
-    }
-    lds_dma_barrier();
-    const int partner = wave ^ 2;
-    const bool do_relu = co < a.relu_upto;
-    // accumulator row r of lane half hh is tile (ty, tx) = (r >> 2, (r & 3) + 4*hh): the row offset of a store is uniform per r,
-    // only the 8*hh column shift and the channel are per lane -> one lane base pointer, scalar offsets
-    const int ow_l = ow0 + 8 * hh;
-    float* ybase = P.y + (((long)n * H + oh0 + fh) * W + ow_l) * a.y_cs + a.y_co + co;
-    float gs = 0.f, gss = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ty = r >> 2, txr = r & 3;
-        const float2 other = ex[(partner * 16 + r) * 64 + lane];
-        const bool row_ok = cvalid && (oh0 + 2 * ty + fh < H);
-        float* yp = ybase + ((long)(2 * ty) * W + 2 * txr) * a.y_cs;
-        float v0 = (keep[r][0] + other.x) * sc + sh, v1 = (keep[r][1] + other.y) * sc + sh;
-        if (do_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        const bool ok0 = row_ok && ow_l + 2 * txr < W, ok1 = row_ok && ow_l + 2 * txr + 1 < W;
-        if (ok0) { yp[0] = v0; gs += v0; gss = fmaf(v0, v0, gss); }
-        if (ok1) { yp[a.y_cs] = v1; gs += v1; gss = fmaf(v1, v1, gss); }
-    }
-    // fused GroupNorm statistics of the NEXT layer's normalisation (fcos.py:182-186): fold the lane's 32 outputs over the
-    // channels of its group (adjacent lanes) and the two column halves, one {sum, sumsq} record per (tile, row parity, group)
-    if (a.gn_ws) {
-        for (int o = 1; o < a.gn_cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
-        gs += __shfl_xor(gs, 32);
-        gss += __shfl_xor(gss, 32);
-        if (cvalid && hh == 0 && (li & (a.gn_cpg - 1)) == 0) {
-            double* o = a.gn_ws + (((long)bx * 2 + fh) * a.gn_groups + co / a.gn_cpg) * 2;
-            o[0] = (double)gs;
-            o[1] = (double)gss;
-        }
-    }
-}
-
-// Register-weights form of the 2-workgroup kernel (tune_wm 5).  What bounds the LDS-DMA form above is a latency chain, not
-// throughput: a step's weight piece can only be requested one step ahead (two 16 KiB LDS buffers are all that fit next to V and the
-// halo at two workgroups per CU) and an L2 round trip under load is about as long as a step, so every step ends up waiting for it
-// (tools/probe/trace_wino.py).  Here each lane loads its own U operand pieces from global memory into registers TWO steps ahead
-// (three register buffers; layout R = one contiguous KiB per wave load, cmk_conv_desc.w_wino_r), the freed 32 KiB of LDS hold a
-// second V buffer so the input transform of chunk c+1 overlaps the MFMAs of chunk c, and there are two barriers per chunk instead
-// of four, none of which waits for memory.
 constexpr int R_LDS_BYTES = (S_SH + 2 * S_SV) * 4;
 __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1079,7 +566,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
         *reinterpret_cast<f32x4*>(dst + 3 * 32 * 16) = v3;
     };
 
-    const int co = co0 + ng * 32 + li;       // epilogue scale/shift fetched early (see conv_wino4s_kernel)
+    // epilogue scale/shift are fetched here, long before they are needed: loaded in the epilogue (under the cout mask) the compiler's
+    // waitcnt bookkeeping could not prove them landed at the joins of the masked store blocks and put `s_waitcnt vmcnt(0)` in front
+    // of every one of a lane's 32 global stores, i.e. each store waited for the previous one to retire
+    const int co = co0 + ng * 32 + li;
     const bool cvalid = co < a.Cout;
     const float sc = P.scale[min(co, a.Cout - 1)];
     const float sh = P.shift[min(co, a.Cout - 1)];
@@ -1232,14 +722,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
     }
 }
 
-static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
+static int launch_wino(ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
         if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -1247,18 +733,13 @@ static int launch_wino(ConvArgs& a, int waves8, hipStream_t st) {
     for (int i = 0; i < a.nprob; ++i) {
         ConvProblem& p = a.p[i];
         p.tile_begin = blocks;
-        p.tiles_h = cdiv(p.Ho, waves8 >= 2 ? 8 : 16);
+        p.tiles_h = cdiv(p.Ho, 8);
         p.tiles_w = cdiv(p.Wo, 16);
         blocks += p.N * p.tiles_h * p.tiles_w;
     }
     a.grid_y = cdiv(a.Cout, 64);
     a.total_tiles = blocks;
-    if (waves8 == 3)
-        hipLaunchKernelGGL(conv_wino4s_kernel, dim3(((blocks + 7) / 8) * 8 * a.grid_y), dim3(256), S_LDS_BYTES, st, a);
-    else if (waves8 == 2)
-        hipLaunchKernelGGL(conv_wino4r_kernel, dim3(((blocks + 7) / 8) * 8 * a.grid_y), dim3(256), R_LDS_BYTES, st, a);
-    else
-        hipLaunchKernelGGL(conv_wino8_kernel, dim3(blocks * a.grid_y), dim3(512), W_LDS_BYTES, st, a);
+    hipLaunchKernelGGL(conv_wino4r_kernel, dim3(((blocks + 7) / 8) * 8 * a.grid_y), dim3(256), R_LDS_BYTES, st, a);
     return check_launch("conv_wino");
 }
 
@@ -1440,18 +921,16 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const int cout32 = (d->Cout + 31) / 32;
     const int taps = d->ksize * d->ksize;
     hipStream_t st = (hipStream_t)stream;
-    if (d->tune_wm == 4 || d->tune_wm == 5 || d->tune_wm == 6) {          // Winograd F(2x2,3x3) (4 = 8 waves / 1 workgroup per CU, 6 = 4 waves x 2 workgroups per CU): 3x3 stride 1, no residual / input ReLU
-        const float* wu = d->tune_wm == 5 ? d->w_wino_r : d->w_wino;
-        if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !wu || (d->in_scale && d->tune_wm == 4))
+    if (d->tune_wm == 5) {          // Winograd F(2x2,3x3): 3x3 stride 1, no residual / input ReLU
+        if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino)
             return fail(CMK_EINVAL, "conv: Winograd variant not available for this conv%s", "");
         if (d->splitk > 1) return fail(CMK_EINVAL, "conv: split-K is a direct-kernel feature%s", "");
         if (d->gn_ws) {
-            if (d->tune_wm == 4) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics need a 2-WG Winograd form%s", "");
             int rc = setup_gn(a, d);
             if (rc) return rc;
         }
-        a.w = wu;
-        return launch_wino(a, d->tune_wm - 3, st);
+        a.w = d->w_wino;
+        return launch_wino(a, st);
     }
     a.ksplit = d->splitk > 1 ? d->splitk : 1;
     a.ws = d->splitk_ws;
@@ -1468,19 +947,19 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     }
     Variant v;
     if (d->tune_wm || d->tune_sc || d->tune_wn) {      // the caller measured and picked a variant
-        if (d->gn_ws) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics are only produced by the Winograd form (tune_wm 6)%s", "");
+        if (d->gn_ws) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics are only produced by the Winograd form (tune_wm 5)%s", "");
         v = Variant{d->tune_wm, d->tune_sc, d->tune_wn};
         if (!variant_ok(taps, d->stride, cout32, v.wm, v.sc, v.wn)) return fail(CMK_EINVAL, "conv: variant not available for this shape%s", "");
     } else {
         // untuned default: the 2-WG/CU Winograd form wins on every 3x3 stride-1 shape measured (tools/bench_wino.py), so take it
         // whenever the caller packed the transformed weights; otherwise the direct-kernel cost model decides
-        if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && (d->w_wino || d->w_wino_r) && d->Cin >= 32 && d->splitk <= 1) {
+        if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && d->w_wino && d->Cin >= 32 && d->splitk <= 1) {
             if (d->gn_ws) {
                 int rc = setup_gn(a, d);
                 if (rc) return rc;
             }
-            a.w = d->w_wino_r ? d->w_wino_r : d->w_wino;
-            return launch_wino(a, d->w_wino_r ? 2 : 3, st);
+            a.w = d->w_wino;
+            return launch_wino(a, st);
         }
         if (d->gn_ws) return fail(CMK_EINVAL, "conv: fused GroupNorm statistics are only produced by the Winograd form%s", "");
         // stride-2 3x3 on a map of at most 16x16 outputs (maskiou conv4 14->7, P6/P7): the spatial tiles would be mostly empty
@@ -1534,7 +1013,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
         if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
-            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || b->w_wino_r != a->w_wino_r || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
+            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
             b->gn_ws != a->gn_ws || b->gn_groups != a->gn_groups || b->splitk > 1)
             return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
     }

@@ -91,28 +91,16 @@ def _wino_u(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
-    """Packed U for the LDS-DMA Winograd kernels (cmk_conv_desc.w_wino): [Cin/16][ceil(Cout/64)][16 freq][64 co][16 ci]."""
+    """Packed U for the Winograd kernel (cmk_conv_desc.w_wino):
+    [chunk][ntile][step 4][fh 2][ng 2][fl 2][piece 2][lane = 32*hh + li][4] with freq = step*4 + fh*2 + fl (step order),
+    co = ng*32 + li, ci = 8*hh + 4*piece + j — every operand load of a wave is one contiguous KiB."""
     lib = _lib.load()
     up = _wino_u(w)
     nc, nt = up.shape[0], up.shape[1]
-    # the HBM image is the LDS image: 16-byte chunk p of row co holds logical chunk p ^ ((co >> 2) & 3)  (bank-conflict-free
-    # ds_read_b128 without padding; global_load_lds copies it verbatim)
-    co = torch.arange(64)
-    src_chunk = torch.arange(4)[None, :] ^ ((co[:, None] >> 2) & 3)                                      # [co][p] -> logical chunk
-    up = up.reshape(nc, nt, 16, 64, 4, 4)
-    up = torch.gather(up, 4, src_chunk[None, None, None, :, :, None].expand(nc, nt, 16, 64, 4, 4)).reshape(nc, nt, 16, 64, 16).contiguous()
-    assert up.numel() == lib.cmk_wino_packed_floats(w.shape[0], w.shape[1])
-    return up
-
-
-def pack_wino_weight_r(w: torch.Tensor) -> torch.Tensor:
-    """Packed U for the register-weights Winograd kernel (cmk_conv_desc.w_wino_r):
-    [chunk][ntile][step 4][fh 2][ng 2][fl 2][piece 2][lane = 32*hh + li][4] with freq = step*4 + fh*2 + fl (step order),
-    co = ng*32 + li, ci = 8*hh + 4*piece + j — every operand load of a wave is one contiguous KiB."""
-    up = _wino_u(w)
-    nc, nt = up.shape[0], up.shape[1]
     r = up.reshape(nc, nt, 4, 2, 2, 2, 32, 2, 2, 4)               # [chunk][nt][g][fh][fl][ng][li][hh][piece][j]
-    return r.permute(0, 1, 2, 3, 5, 4, 8, 7, 6, 9).contiguous().reshape(nc, nt, 16, 64, 16)
+    r = r.permute(0, 1, 2, 3, 5, 4, 8, 7, 6, 9).contiguous().reshape(nc, nt, 16, 64, 16)
+    assert r.numel() == lib.cmk_wino_packed_floats(w.shape[0], w.shape[1])
+    return r
 
 
 class PackedConv:
@@ -126,9 +114,7 @@ class PackedConv:
         self.cin_pad = (self.cin + 15) // 16 * 16
         self.stride = stride
         self.w = pack_conv_weight(weight).to(device)
-        wino = self.k == 3 and stride == 1 and self.cin >= 16
-        self.w_wino = pack_wino_weight(weight).to(device) if wino else None
-        self.w_wino_r = pack_wino_weight_r(weight).to(device) if wino else None
+        self.w_wino = pack_wino_weight(weight).to(device) if (self.k == 3 and stride == 1 and self.cin >= 16) else None
         self.scale = (torch.ones(self.cout) if scale is None else scale.detach().float().cpu()).contiguous().to(device)
         self.shift = (torch.zeros(self.cout) if shift is None else shift.detach().float().cpu()).contiguous().to(device)
 
@@ -146,7 +132,6 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
     d.x, d.x_cs, d.x_co = x.t.data_ptr(), x.cs, x.co
     d.w = pc.w.data_ptr()
     d.w_wino = pc.w_wino.data_ptr() if getattr(pc, "w_wino", None) is not None else None
-    d.w_wino_r = pc.w_wino_r.data_ptr() if getattr(pc, "w_wino_r", None) is not None else None
     d.scale, d.shift = pc.scale.data_ptr(), pc.shift.data_ptr()
     if res is not None:
         d.res, d.res_cs, d.res_co = res.t.data_ptr(), res.cs, res.co
@@ -253,7 +238,7 @@ def _tune(descs, n, key) -> None:
     if small and d0.ksize == 3:
         cands += [(7, 32, wn, sk) for wn in (1, 2, 4) for sk in sks]      # gather form
     if ALLOW_WINOGRAD:
-        cands += [(4, 16, 2, 1), (5, 16, 2, 1), (6, 16, 2, 1)]   # fused Winograd F(2x2,3x3): 8-wave, register-weights 2-WG, LDS-DMA 2-WG forms
+        cands += [(5, 16, 2, 1)]                  # fused Winograd F(2x2,3x3)
     for tv in cands:
         ws = _set_variant(descs, n, tv)
         if run() != 0:
@@ -327,7 +312,7 @@ def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Te
                   eps: float = 1e-5, in_affine=None):
     """Tower conv (no activation) over several levels + the statistics of the GroupNorm that follows (fcos.py:182-186).
     Returns (raw conv outputs, [(scale, shift)] per level) — the affine is applied by the NEXT conv while staging.
-    When the Winograd 2-WG kernel runs the conv, its epilogue produces the statistics (no pass over the output)."""
+    When the Winograd kernel runs the conv, its epilogue produces the statistics (no pass over the output)."""
     lib = _lib.load()
     n = len(xs)
     pc = pcs[0]
@@ -353,7 +338,7 @@ def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Te
 
     d0 = descs[0]
     cpg = pc.cout // groups if groups > 0 and pc.cout % groups == 0 else 0
-    wino = d0.tune_wm in (5, 6) or ((d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0) and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
+    wino = d0.tune_wm == 5 or ((d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0) and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
     fused = wino and 0 < cpg <= 32 and (cpg & (cpg - 1)) == 0 and all(x.t.shape[0] == xs[0].t.shape[0] for x in xs)
     if not fused:
         launch()
@@ -653,8 +638,8 @@ def _kernel_name(taps, stride, tv) -> str:
     """The template instantiation rocprofv3 will report: conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>."""
     if not tv or tuple(tv[:3]) == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
-    if tv[0] in (4, 5, 6):
-        return "cmk::conv_wino{}_kernel".format({4: "8", 5: "4r", 6: "4s"}[tv[0]])
+    if tv[0] == 5:
+        return "cmk::conv_wino4r_kernel"
     wm, sc, wn = tv[:3]
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)

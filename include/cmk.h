@@ -52,18 +52,13 @@ typedef struct {
      * 9 taps x Cin/16 chunks, each A row gathered per tap — for maps too small to fill the spatial tiles (the 14->7 maskiou conv
      * maskiou_head.py:84, P6/P7 fpn.py:32-35); same K order, so again bitwise identical to the tiled variants. */
     int tune_wm; int tune_sc; int tune_wn;
-    /* tune_wm == 6 (4 waves, two workgroups per CU, weights by LDS-DMA) or 4 (8 waves, one workgroup per CU) selects the
-     * fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual): same fp32 arithmetic on the
-     * matrix pipe with 2.25x fewer multiplies; results differ from the direct kernel by fp32 rounding only.  It needs the
-     * weights pre-transformed to U = G g G^T, packed [Cin/16][ceil(Cout/64)][16 freq in step order][64][16] (cmk_wino_packed_floats);
-     * step g streams the frequencies {2g, 2g+1, 8+2g, 9+2g} of the row-major 4x4 frequency grid; within a 64-byte row
-     * (one co, 16 ci) the 16-byte chunk at position p holds logical chunk p ^ ((co >> 2) & 3) (the LDS swizzle). */
+    /* tune_wm == 5 selects the fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual; the default for such convs when w_wino
+     * is given): same fp32 arithmetic on the matrix pipe with 2.25x fewer multiplies; results differ from the direct kernel by fp32
+     * rounding only.  It needs the weights pre-transformed to U = G g G^T (cmk_wino_packed_floats floats), packed
+     * [Cin/16][ceil(Cout/64)][step 4][fh 2][ng 2][fl 2][piece 2][lane 64][4 floats]: frequency (row-major index of the 4x4 grid) =
+     * 8*fh + 2*step + fl, output channel = ntile*64 + ng*32 + (lane & 31), input channel = chunk*16 + 8*(lane >> 5) + 4*piece + j —
+     * every operand load of a wave is one contiguous KiB. */
     const float* w_wino;
-    /* tune_wm == 5 selects the register-weights form of that kernel (weights fetched two steps ahead into registers, double-buffered
-     * transform; the default when w_wino_r is given).  Same U values, packed [Cin/16][ceil(Cout/64)][step 4][fh 2][ng 2][fl 2][piece 2]
-     * [lane 64][4 floats]: frequency = the step-ordered index step*4 + fh*2 + fl of the list above, output channel = ntile*64 + ng*32 +
-     * (lane & 31), input channel = chunk*16 + 8*(lane >> 5) + 4*piece + j.  Same size as w_wino (cmk_wino_packed_floats). */
-    const float* w_wino_r;
     /* optional fused GroupNorm+ReLU of the PRODUCER (fcos.py:182-186): per (image, input channel) x' = relu(x*in_scale + in_shift)
      * is applied while the input tile is staged, so the normalised tensor is never written; arrays of N*Cin floats from
      * cmk_groupnorm_affine.  Supported by the direct kernels and Winograd form 6. */
@@ -74,7 +69,7 @@ typedef struct {
      * maskiou_head.py:116) whose M x N tiles cannot fill 256 CUs.  0/1 = off. */
     int splitk; float* splitk_ws;
     /* optional fused GroupNorm STATISTICS of this conv's output (the GroupNorm that follows it, fcos.py:182-186): only with
-     * tune_wm == 6, relu_upto == 0 and Cout/gn_groups a power of two <= 32.  The kernel writes {sum, sum of squares} per
+     * tune_wm == 5, relu_upto == 0 and Cout/gn_groups a power of two <= 32.  The kernel writes {sum, sum of squares} per
      * (spatial tile of 8x16 outputs, row parity, group) to gn_ws as doubles: record index ((tile*2 + parity)*gn_groups + group),
      * tiles numbered image-major per problem (for _multi: problems back to back) with cmk_conv_gn_tiles(H, W) tiles per image;
      * cmk_groupnorm_affine_tiles turns them into the per-(image, channel) scale/shift.  NULL = off. */

@@ -16,7 +16,7 @@ def timeit(d, it=4):
     for _ in range(it): rc = lib.cmk_conv2d_nhwc(ctypes.byref(d), ops._stream())
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
-print("%-8s %9s %9s %9s %9s %9s %9s %9s %9s" % ("layer", "direct ms", "TF", "wino8 ms", "algTF", "wino4r ms", "algTF", "wino4s ms", "algTF"))
+print("%-8s %9s %9s %9s %9s" % ("layer", "direct ms", "TF", "wino ms", "algTF"))
 for name, h, w, cin, cout in SHAPES:
     n = 400 if name == "roi" else B
     x = View(torch.randn((n, h, w, cin), device=dev)); pc = ops.PackedConv(torch.randn((cout, cin, 3, 3)) * 0.05, None, None, dev)
@@ -28,11 +28,7 @@ for name, h, w, cin, cout in SHAPES:
             for sc in (16, 32):
                 d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = wm, sc, wn
                 if lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) == 0: best = min(best, timeit(d[0]))
-    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 4, 16, 2
-    tw8 = timeit(d[0])
-    d[0].tune_wm = 5
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 5, 16, 2
     tw4r = timeit(d[0])
-    d[0].tune_wm = 6
-    tw4s = timeit(d[0])
     fl = 2.0 * n * h * w * cin * cout * 9
-    print("%-8s %9.3f %9.1f %9.3f %9.1f %9.3f %9.1f %9.3f %9.1f" % (name, best, fl / best / 1e9, tw8, fl / tw8 / 1e9, tw4r, fl / tw4r / 1e9, tw4s, fl / tw4s / 1e9))
+    print("%-8s %9.3f %9.1f %9.3f %9.1f" % (name, best, fl / best / 1e9, tw4r, fl / tw4r / 1e9))

@@ -17,7 +17,7 @@ for k in range(1, 5):
     pc = ops.PackedConv(w, None, b, "cuda")
     ref = F.relu(F.conv2d(xin.t.permute(0, 3, 1, 2).cpu().double(), w.double(), b.double(), padding=1)).float()
     res = {}
-    for name, tv in (("direct", (2, 16, 4)), ("wino4s", (6, 16, 2)), ("wino8", (4, 16, 2)), ("wino4", (3, 16, 2))):
+    for name, tv in (("direct", (2, 16, 4)), ("wino", (5, 16, 2))):
         y = View(torch.empty((50, 14, 14, 256), device="cuda"))
         d = (_lib.ConvDesc * 1)(); ops._fill_desc(d[0], xin, pc, y, True, None, None, False, False)
         d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = tv

@@ -1,7 +1,7 @@
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
-WM = int(sys.argv[1]) if len(sys.argv) > 1 else 6          # 6 = LDS-DMA 2-WG form, 5 = register-weights 2-WG form, 4 = 8-wave form
+WM = 5          # the Winograd kernel
 from centermask2_amd import ops, _lib
 from centermask2_amd.ops import View
 lib = _lib.load()
