@@ -602,12 +602,26 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
     //   steps 2-3: MFMAs + the halo of chunk c+2 registers -> LDS (its global loads were issued in step 0)
     //   barrier (V(c+1) and the new halo are visible; V(c) may be overwritten)
     const int total_steps = nchunks * 4;
+    // prologue: the halos of chunks 0 AND 1 and the first weight pieces are requested together, so only one memory round trip is
+    // exposed before the first MFMA (chunk 1's halo waits in registers until chunk 0's has been transformed)
     load_H(0);
+    f32x4 h_next[S_H_ITERS], sc_next = in_sc, sh_next = in_sh;
+    {
+        const int c1 = min(1, nchunks - 1);
+#pragma unroll
+        for (int it = 0; it < S_H_ITERS; ++it) h_next[it] = *reinterpret_cast<const f32x4*>(xin + g_off[it] + c1 * 16);
+        if (has_aff) {
+            sc_next = *reinterpret_cast<const f32x4*>(aff_s + c1 * 16);
+            sh_next = *reinterpret_cast<const f32x4*>(aff_b + c1 * 16);
+        }
+    }
     store_H();
     __syncthreads();
     transform_part(0, 0);
     transform_part(1, 0);
-    load_H(min(1, nchunks - 1));
+#pragma unroll
+    for (int it = 0; it < S_H_ITERS; ++it) h_stage[it] = h_next[it];
+    in_sc = sc_next; in_sh = sh_next;
     __syncthreads();
     store_H();
     // weight operands are fetched two steps ahead into four register buffers (index = step % 4 = g; a buffer is live for two
