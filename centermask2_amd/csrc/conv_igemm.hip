@@ -615,6 +615,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
             sh_next = *reinterpret_cast<const f32x4*>(aff_b + c1 * 16);
         }
     }
+    // weight operands are fetched two steps ahead into four register buffers (index = step % 4 = g; a buffer is live for two
+    // steps, so three are held at a time); the first two pieces are requested here, with the halos
+    constexpr int PF = 2;
+#pragma unroll
+    for (int t = 0; t < PF; ++t) load_B(min(t, total_steps - 1), t);
     store_H();
     __syncthreads();
     transform_part(0, 0);
@@ -624,11 +629,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
     in_sc = sc_next; in_sh = sh_next;
     __syncthreads();
     store_H();
-    // weight operands are fetched two steps ahead into four register buffers (index = step % 4 = g; a buffer is live for two
-    // steps, so three are held at a time)
-    constexpr int PF = 2;
-#pragma unroll
-    for (int t = 0; t < PF; ++t) load_B(min(t, total_steps - 1), t);
     for (int c = 0; c < nchunks; ++c) {
         const int cnn = min(c + 2, nchunks - 1);
         const float* A = Abase + (c & 1) * S_SV;
