@@ -61,7 +61,7 @@ typedef struct {
     const float* w_wino;
     /* optional fused GroupNorm+ReLU of the PRODUCER (fcos.py:182-186): per (image, input channel) x' = relu(x*in_scale + in_shift)
      * is applied while the input tile is staged, so the normalised tensor is never written; arrays of N*Cin floats from
-     * cmk_groupnorm_affine.  Supported by the direct kernels and Winograd form 6. */
+     * cmk_groupnorm_affine.  Supported by the direct kernels and the Winograd kernel. */
     const float* in_scale; const float* in_shift;
     /* split-K (direct kernels incl. the gather form, one problem, res_mode 0|1): splitk >= 2 workgroup rows each own 1/splitk of the
      * 16-channel K chunks (K chunks % (2*splitk) == 0) and write raw partial sums to splitk_ws (splitk * N*Ho*Wo * cmk_conv_cout_pad(Cout)

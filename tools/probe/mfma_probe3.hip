@@ -1,6 +1,6 @@
 // VMEM-cost probe: 16 MFMAs per step (two alternating accumulators) plus NL vector-memory instructions per step, each a
 // 64-lane x 16 B read of an L2-resident buffer (MODE 0: global_load_dwordx4 into registers, consumed one step later;
-// MODE 1: global_load_lds_dwordx4 into LDS, drained by s_waitcnt vmcnt(0) + barrier at the next step like the Winograd kernel).
+// MODE 1: global_load_lds_dwordx4 into LDS, drained by s_waitcnt vmcnt(0) + barrier at the next step like the earlier LDS-DMA Winograd forms).
 // usage: mfma_probe3   Build: hipcc --offload-arch=gfx950 -O3
 #include <hip/hip_runtime.h>
 #include <cstdio>
