@@ -556,11 +556,23 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const GnTileLeve
     if (part < parts) {
         const long r0 = ((long)L.tile_begin[l] + (long)n * L.tiles[l]) * 2;
         const int nrec = L.tiles[l] * 2;
-        for (int r = part; r < nrec; r += parts) {
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;      // four independent chains: the loads overlap
+        int r = part;
+        for (; r + 3 * parts < nrec; r += 4 * parts) {
+            const double* w = ws + ((r0 + r) * groups + g) * 2;
+            const long st = (long)parts * groups * 2;
+            a += w[0]; b += w[1];
+            a1 += w[st]; b1 += w[st + 1];
+            a2 += w[2 * st]; b2 += w[2 * st + 1];
+            a3 += w[3 * st]; b3 += w[3 * st + 1];
+        }
+        for (; r < nrec; r += parts) {
             const double* w = ws + ((r0 + r) * groups + g) * 2;
             a += w[0];
             b += w[1];
         }
+        a += a1 + a2 + a3;
+        b += b1 + b2 + b3;
     }
     rs[threadIdx.x] = a;
     rss[threadIdx.x] = b;
