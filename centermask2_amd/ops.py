@@ -190,13 +190,25 @@ def save_tuned(path: str) -> None:
         json.dump({_key_to_str(k): list(v) for k, v in sorted(_TUNED.items(), key=lambda kv: _key_to_str(kv[0]))}, f, indent=0)
 
 
+def _variant_on_menu(tv) -> bool:
+    """(wm, sc, wn[, splitk]) names a kernel this library has (older tables may carry variants that were removed since)."""
+    wm, sc, wn = tv[:3]
+    sk = tv[3] if len(tv) > 3 else 1
+    return (wm in (1, 2, 5, 7) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
+
+
 def load_tuned(path: str) -> int:
+    """Read a measured variant table; entries naming a variant that is not on the menu are dropped (that problem falls back to the
+    library default / the start-up tuner), so a stale table cannot break a run."""
     import json
     with open(path) as f:
         table = json.load(f)
+    n = 0
     for k, v in table.items():
-        _TUNED[_str_to_key(k)] = tuple(v)
-    return len(table)
+        if _variant_on_menu(v):
+            _TUNED[_str_to_key(k)] = tuple(v)
+            n += 1
+    return n
 
 
 def _out_pixels(d) -> int:

@@ -107,6 +107,28 @@ def test_product_never_imports_oracle():
                 assert not pat.search(open(os.path.join(dirpath, f)).read()), f
 
 
+def test_shipped_variant_tables_name_existing_kernels(tmp_path):
+    """The measured conv-variant tables bench.py loads must only name variants the library still has; stale entries are dropped."""
+    import glob, json, os
+    from centermask2_amd import ops
+    tables = glob.glob(os.path.join(os.path.dirname(ops.__file__), "tuned", "*.json"))
+    assert tables
+    for path in tables:
+        table = json.load(open(path))
+        assert table and all(ops._variant_on_menu(v) for v in table.values()), path
+        assert all(ops._key_to_str(ops._str_to_key(k)) == k for k in table)
+    stale = tmp_path / "stale.json"
+    key = next(iter(json.load(open(tables[0]))))
+    stale.write_text(json.dumps({key: [6, 16, 2]}))          # a Winograd form that was removed
+    saved = dict(ops._TUNED)
+    try:
+        ops._TUNED.clear()
+        assert ops.load_tuned(str(stale)) == 0 and not ops._TUNED
+    finally:
+        ops._TUNED.clear()
+        ops._TUNED.update(saved)
+
+
 def test_structures():
     from centermask2_amd.structures import Boxes, FakeImageList, ImageList, Instances
     b = Boxes(torch.tensor([[0., 0., 10., 20.], [5., 5., 5., 9.]]))
