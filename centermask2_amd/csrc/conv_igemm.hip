@@ -455,6 +455,9 @@ constexpr int S_SH = S_HALO * PST;                 // floats
 constexpr int S_SV = 16 * 32 * 16;
 constexpr int S_H_ITERS = (S_HALO * 4 + 255) / 256;
 constexpr int R_LDS_BYTES = (S_SH + 2 * S_SV) * 4;
+// AFF: the producer's GroupNorm+ReLU is applied while the halo is staged (FCOS tower convs 2-4 and the predictors).  Without it the
+// staging registers of the affine are free and the weights are fetched three steps ahead instead of two.
+template <bool AFF>
 __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sH = smem;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
         g_off[it] = off;
     }
     f32x4 h_stage[S_H_ITERS];
-    const bool has_aff = P.in_scale != nullptr;      // fused GroupNorm apply + ReLU of the producer
+    constexpr bool has_aff = AFF;                    // fused GroupNorm apply + ReLU of the producer
     const float* aff_s = has_aff ? P.in_scale + (long)n * a.Cin + (tid & 3) * 4 : nullptr;
     const float* aff_b = has_aff ? P.in_shift + (long)n * a.Cin + (tid & 3) * 4 : nullptr;
     f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
@@ -615,9 +618,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
             sh_next = *reinterpret_cast<const f32x4*>(aff_b + c1 * 16);
         }
     }
-    // weight operands are fetched two steps ahead into four register buffers (index = step % 4 = g; a buffer is live for two
-    // steps, so three are held at a time); the first two pieces are requested here, with the halos
-    constexpr int PF = 2;
+    // weight operands are fetched PF steps ahead into four register buffers (index = step % 4 = g; a buffer is live for PF steps);
+    // the first PF pieces are requested here, with the halos
+    constexpr int PF = AFF ? 2 : 3;
 #pragma unroll
     for (int t = 0; t < PF; ++t) load_B(min(t, total_steps - 1), t);
     store_H();
@@ -739,7 +742,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
 static int launch_wino(ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
         if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -753,7 +758,11 @@ static int launch_wino(ConvArgs& a, hipStream_t st) {
     }
     a.grid_y = cdiv(a.Cout, 64);
     a.total_tiles = blocks;
-    hipLaunchKernelGGL(conv_wino4r_kernel, dim3(((blocks + 7) / 8) * 8 * a.grid_y), dim3(256), R_LDS_BYTES, st, a);
+    const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y);
+    if (a.p[0].in_scale)          // all problems of a launch agree on this (validated)
+        hipLaunchKernelGGL(conv_wino4r_kernel<true>, grid, dim3(256), R_LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL(conv_wino4r_kernel<false>, grid, dim3(256), R_LDS_BYTES, st, a);
     return check_launch("conv_wino");
 }
 
