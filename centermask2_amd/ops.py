@@ -346,7 +346,7 @@ def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Te
         e0.record()
         check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi")
         e1.record()
-        PROFILE.append((_kernel_name(taps, 1, _TUNED.get(key)), flops, nbytes, e0, e1, None))
+        PROFILE.append((_kernel_name(taps, 1, _TUNED.get(key), in_affine is not None), flops, nbytes, e0, e1, None))
 
     d0 = descs[0]
     cpg = pc.cout // groups if groups > 0 and pc.cout % groups == 0 else 0
@@ -646,16 +646,16 @@ PROFILE = None       # when a list, conv2d appends (kernel_key, flops, algorithm
 _conv2d_plain = conv2d
 
 
-def _kernel_name(taps, stride, tv) -> str:
-    """The template instantiation rocprofv3 will report: conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC>."""
+def _kernel_name(taps, stride, tv, aff=False) -> str:
+    """The template instantiation rocprofv3 will report (minus the `void cmk::` prefix and the argument list)."""
     if not tv or tuple(tv[:3]) == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
     if tv[0] == 5:
-        return "cmk::conv_wino4r_kernel"
+        return "conv_wino4r_kernel<{}>".format("true" if aff else "false")
     wm, sc, wn = tv[:3]
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)
-    return "conv_igemm_kernel<{}, {}, {}, {}, {}>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
+    return "conv_igemm_kernel<{}, {}, {}, {}, {}, false>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
 
 
 def conv2d(x, pc, y, **kw):  # noqa: F811
@@ -696,7 +696,7 @@ def conv2d_multi(xs, pcs, ys, **kw):  # noqa: F811
     for i in range(len(xs)):
         _fill_desc(descs[i], xs[i], pcs[i], ys[i], kw.get("relu", False), kw.get("relu_upto"), None, False, False,
                    kw["in_affine"][i] if kw.get("in_affine") is not None else None)
-    PROFILE.append((_kernel_name(taps, 1, _TUNED.get(_problem_key(descs, len(xs)))), flops, nbytes, e0, e1, None))
+    PROFILE.append((_kernel_name(taps, 1, _TUNED.get(_problem_key(descs, len(xs))), kw.get("in_affine") is not None), flops, nbytes, e0, e1, None))
 
 
 # ---------------------------------------------------------------------------------------------------------------

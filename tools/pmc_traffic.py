@@ -20,7 +20,7 @@ fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in fetch:
-    if k.startswith("conv_igemm") or k.startswith("cmk::"):
+    if k.startswith("conv_") or k.startswith("cmk::"):
         out[k] = {"fetch_bytes_per_launch": 2.0 * 1024.0 * fetch[k], "write_bytes_per_launch": 1024.0 * write.get(k, 0.0),
                   "hbm_bytes_per_launch": 2.0 * 1024.0 * fetch[k] + 1024.0 * write.get(k, 0.0), "launches_sampled": nf[k],
                   "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count of wide reads), WRITE_SIZE KiB x1024"}
