@@ -27,6 +27,7 @@ class ConvDesc(Structure):
         ("in_scale", c_void_p), ("in_shift", c_void_p),
         ("splitk", c_int), ("splitk_ws", c_void_p),
         ("gn_ws", c_void_p), ("gn_groups", c_int),
+        ("w_wino6", c_void_p),
     ]
 
 
@@ -44,6 +45,8 @@ SIGNATURES = {
     "cmk_conv_packed_floats": (c_int64, [c_int, c_int, c_int]),
     "cmk_conv_cout_pad": (c_int, [c_int]),
     "cmk_wino_packed_floats": (c_int64, [c_int, c_int]),
+    "cmk_wino6_packed_floats": (c_int64, [c_int, c_int]),
+    "cmk_conv_gn_records": (c_int, [c_int, c_int, c_int]),
     "cmk_dwconv3x3_nhwc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_stem_conv_nchw3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_maxpool3x3s2_ceil_nhwc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -53,7 +56,7 @@ SIGNATURES = {
     "cmk_groupnorm_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "cmk_groupnorm_affine_multi": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                            POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
-    "cmk_groupnorm_affine_tiles": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+    "cmk_groupnorm_affine_tiles": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                            POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     "cmk_conv_gn_tiles": (c_int, [c_int, c_int]),
     "cmk_fcos_select": (c_int, [POINTER(FcosLevel), c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,

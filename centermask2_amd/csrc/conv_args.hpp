@@ -1,0 +1,59 @@
+// Shared by the conv kernels of libcmk_hip.so: launch arguments (one struct passed by value) and vector types.
+#pragma once
+#include "cmk_common.hpp"
+
+namespace cmk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PST = 20;      // LDS row pitch in floats: 16 channels + 4 pad
+constexpr int MAXP = 5;      // problems (FPN levels) per launch
+constexpr int LDS_CU = 160 * 1024;
+
+// workgroups per CU the register budget allows (accumulators: 16 VGPRs per 32x32 tile)
+__host__ __device__ constexpr int occ_of(int wm, int wn, int stride) { return (stride == 1 && (wm == 1 ? wn <= 5 : wn <= 2)) ? 3 : 2; }
+
+struct ConvProblem {
+    const float* x; float* y; const float* scale; const float* shift;
+    const float* in_scale; const float* in_shift;   // optional (N, Cin): x' = relu(x * in_scale + in_shift) while staging (fused GroupNorm+ReLU)
+    int N, H, W, Ho, Wo;
+    int tiles_h, tiles_w, tile_begin;
+    long total_pix;  // N*Ho*Wo
+};
+
+struct ConvArgs {
+    ConvProblem p[MAXP];
+    int nprob;
+    const float* w; const float* res;
+    int Cin, Cout;
+    int x_cs, x_co, y_cs, y_co, res_cs, res_co, res_mode, Hr, Wr;
+    int relu_upto, in_relu;
+    int cout_pad;
+    int total_tiles;   // spatial tiles of all problems (XCD-aware kernels pad the grid to a multiple of 8 tiles)
+    int ksplit;        // split-K: blockIdx.y owns an (even) range of the 16-channel chunks and writes raw partial sums to ws
+    float* ws;         // [ksplit][total_pix][cout_pad]
+    double* gn_ws;     // Winograd 2-WG form: per (spatial tile, row parity, group) partial {sum, sum of squares} of the outputs (fused GroupNorm statistics)
+    int gn_cpg, gn_groups;
+    int ga_stride;     // gather form (GA): stride of the 3x3 conv whose taps are walked as 9x more K chunks
+    int grid_y;   // N tiles; the N-tile index is the FASTEST block coordinate so the workgroups sharing an input tile run together (L2 reuse)
+};
+
+// per-device one-time kernel attribute set-up (hipFuncSetAttribute is per device; a process may drive several)
+struct DeviceOnce {
+    unsigned char done[64] = {0};
+    template <typename F>
+    int run(F&& f) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(CMK_ELAUNCH, "hipGetDevice failed%s", "");
+        if (__atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) return CMK_OK;
+        int rc = f();
+        if (rc == CMK_OK) __atomic_store_n(&done[dev], 1, __ATOMIC_RELEASE);   // idempotent: a race only repeats the call
+        return rc;
+    }
+};
+
+// conv_wino6.hip: fused Winograd F(4x4,3x3)
+int launch_wino6(ConvArgs& a, hipStream_t st);
+
+}  // namespace cmk

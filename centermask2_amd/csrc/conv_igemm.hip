@@ -28,44 +28,9 @@
 // fpn.py:27-35; fcos.py:169-200; sam.py:58-83; maskiou_head.py:81-93; nn.Linear maskiou_head.py:89-91.
 #include <stdlib.h>
 
-#include "cmk_common.hpp"
+#include "conv_args.hpp"
 
 namespace cmk {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int PST = 20;      // LDS row pitch in floats: 16 channels + 4 pad
-constexpr int MAXP = 5;      // problems (FPN levels) per launch
-constexpr int LDS_CU = 160 * 1024;
-
-// workgroups per CU the register budget allows (accumulators: 16 VGPRs per 32x32 tile)
-__host__ __device__ constexpr int occ_of(int wm, int wn, int stride) { return (stride == 1 && (wm == 1 ? wn <= 5 : wn <= 2)) ? 3 : 2; }
-
-struct ConvProblem {
-    const float* x; float* y; const float* scale; const float* shift;
-    const float* in_scale; const float* in_shift;   // optional (N, Cin): x' = relu(x * in_scale + in_shift) while staging (fused GroupNorm+ReLU)
-    int N, H, W, Ho, Wo;
-    int tiles_h, tiles_w, tile_begin;
-    long total_pix;  // N*Ho*Wo
-};
-
-struct ConvArgs {
-    ConvProblem p[MAXP];
-    int nprob;
-    const float* w; const float* res;
-    int Cin, Cout;
-    int x_cs, x_co, y_cs, y_co, res_cs, res_co, res_mode, Hr, Wr;
-    int relu_upto, in_relu;
-    int cout_pad;
-    int total_tiles;   // spatial tiles of all problems (XCD-aware kernels pad the grid to a multiple of 8 tiles)
-    int ksplit;        // split-K: blockIdx.y owns an (even) range of the 16-channel chunks and writes raw partial sums to ws
-    float* ws;         // [ksplit][total_pix][cout_pad]
-    double* gn_ws;     // Winograd 2-WG form: per (spatial tile, row parity, group) partial {sum, sum of squares} of the outputs (fused GroupNorm statistics)
-    int gn_cpg, gn_groups;
-    int ga_stride;     // gather form (GA): stride of the 3x3 conv whose taps are walked as 9x more K chunks
-    int grid_y;   // N tiles; the N-tile index is the FASTEST block coordinate so the workgroups sharing an input tile run together (L2 reuse)
-};
 
 template <int TAPS, int STRIDE, int WM, int WN, int SC>
 struct Geo {
@@ -740,14 +705,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino4r_kernel(const ConvArgs a) {
 }
 
 static int launch_wino(ConvArgs& a, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int rc0 = once.run([]() {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
-        if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+        return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    });
+    if (rc0) return rc0;
     int blocks = 0;
     for (int i = 0; i < a.nprob; ++i) {
         ConvProblem& p = a.p[i];
@@ -774,14 +739,13 @@ struct Variant { int wm, sc, wn; };
 template <int TAPS, int STRIDE, int WM, int WN, int SC, bool GA = false>
 static int launch(ConvArgs& a, int grid_y, hipStream_t st) {
     using G = Geo<TAPS, STRIDE, WM, WN, SC>;
-    static bool attr_set = false;
+    static DeviceOnce once;      // one per template instantiation
     auto kern = conv_igemm_kernel<TAPS, STRIDE, WM, WN, SC, GA>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           G::LDS_BYTES);
-        if (e != hipSuccess) return fail(CMK_ELAUNCH, "conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    int rc0 = once.run([kern]() {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    });
+    if (rc0) return rc0;
     int blocks = 0;
     for (int i = 0; i < a.nprob; ++i) {
         ConvProblem& p = a.p[i];
@@ -955,6 +919,17 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         a.w = d->w_wino;
         return launch_wino(a, st);
     }
+    if (d->tune_wm == 6) {          // Winograd F(4x4,3x3): same conditions, its own packed weights
+        if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino6 || (d->Cin & 7))
+            return fail(CMK_EINVAL, "conv: Winograd F(4x4,3x3) variant not available for this conv%s", "");
+        if (d->splitk > 1) return fail(CMK_EINVAL, "conv: split-K is a direct-kernel feature%s", "");
+        if (d->gn_ws) {
+            int rc = setup_gn(a, d);
+            if (rc) return rc;
+        }
+        a.w = d->w_wino6;
+        return launch_wino6(a, st);
+    }
     a.ksplit = d->splitk > 1 ? d->splitk : 1;
     a.ws = d->splitk_ws;
     if (d->tune_wm == 7) {                             // gather form: 3x3 (stride 1|2) as a flattened-pixel GEMM over 9x the K chunks
@@ -1017,6 +992,11 @@ extern "C" int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize) {
 
 extern "C" int cmk_conv_gn_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 15) / 16); }
 
+// {sum, sumsq} records per image that a conv with fused GroupNorm statistics writes: tune_wm 5 -> 2 per 8x16 tile, 6 -> 4 per 12x40 tile
+extern "C" int cmk_conv_gn_records(int H, int W, int tune_wm) {
+    return tune_wm == 6 ? 4 * ((H + 11) / 12) * ((W + 39) / 40) : 2 * ((H + 7) / 8) * ((W + 15) / 16);
+}
+
 extern "C" int64_t cmk_wino_packed_floats(int Cout, int Cin) {
     return (int64_t)((Cin + 15) / 16) * ((Cout + 63) / 64) * 16 * 64 * 16;
 }
@@ -1036,7 +1016,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
         if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
-            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
+            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || b->w_wino6 != a->w_wino6 || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
             b->gn_ws != a->gn_ws || b->gn_groups != a->gn_groups || b->splitk > 1)
             return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
     }

@@ -1,0 +1,408 @@
+// Winograd F(4x4, 3x3) for 3x3 stride-1 convs, fused in one kernel, plain fp32 on the CDNA4 matrix pipe.
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A    per 6x6 input patch d -> 4x4 outputs, summed over input channels: 36 multiplies per
+//   16 outputs = 2.25 per output against 9 (direct) and 4 (F(2x2,3x3), conv_wino4r_kernel) — 1.78x fewer MFMAs than the 2x2 form.
+//   Interpolation points 0, +-1, +-2, inf (Lavin & Gray); every transform is exact-coefficient fp32 arithmetic, U = G g G^T is
+//   computed on the host in fp64 and rounded once.  Measured error of this form on the full model (tools/wino_numerics.py, CPU
+//   emulation of exactly this arithmetic): features/logits rms 1.6e-6 relative (F(2x2): 1.0e-6), labels and locations identical.
+//
+// Shape of the kernel (what differs from conv_wino4r_kernel, and why):
+//   * workgroup = 3 x 10 tiles of 4x4 outputs (12 x 40 pixels: every map width of the model is a multiple of 40) x 32 output
+//     channels, 4 waves, two workgroups per CU.  30 of the 32 MFMA rows carry a tile.  The 36 frequencies of the 6x6 grid are 36
+//     accumulators of 32 tiles x 32 couts; a wave owns 9: grid row a = wave (6 frequencies) and half of row 4 or 5 (3 frequencies).
+//     144 accumulator VGPRs per lane — the register budget shapes everything else.
+//   * the input transform is split.  B^T d B = (column pass) then (row pass):
+//       pass 1 (once per workgroup and 8-channel chunk): thread = (tile row t, halo column, channel quad) — 3 x 42 x 2 = 252 items —
+//         loads the 6 input rows of its item straight from global memory into registers one period ahead (buffer loads: rows and
+//         columns outside the image come back as 0 from the hardware range check, no masks), forms W[t][a][col] = sum_i B^T[a][i] d[4t+i][col]
+//         in place and writes the W image to LDS (28 KiB per chunk, two buffers).  The column pass is shared by horizontally adjacent
+//         tiles, and there is no raw-halo stage in LDS at all;
+//       pass 2 (by the MFMA waves, in registers, right in front of the MFMAs): a lane reads the 5 W values of its tile that one half of
+//         a frequency row needs (conflict-free image, see w6_slot) and forms 3 frequencies with 6 FMAs per channel.
+//     So the 36-plane V image (74 KiB per 16 channels — it would not fit twice beside a second workgroup) never exists, LDS traffic per
+//     MFMA is a fraction of the 2x2 kernel's, the transform costs ~3 VALU instructions per MFMA, and ONE barrier per chunk (36 MFMAs
+//     per wave) is enough — it never waits for memory.
+//   * weights never touch LDS: U is packed so that every operand load of a wave is one contiguous KiB ([chunk][cout tile][wave][9][lane][4])
+//     and is fetched two steps (24 MFMAs) ahead into registers, as in the 2x2 kernel.
+//   * epilogue: each wave reduces its frequencies along b in registers (6 -> 4 and 3 -> 4 partial values per entry), the four waves swap
+//     those through LDS in two rounds, and wave w finishes the 8 tiles of accumulator registers 4w..4w+3: column pass, scale/shift/ReLU,
+//     NHWC stores, GroupNorm statistics.
+//
+// Reference call sites replaced: the same 3x3 stride-1 convs as the 2x2 kernel (vovnet.py:205-219, d2 FPN outputs, fcos.py:169-200,
+// sam.py:58-70, maskiou_head.py:81-88).
+#include "conv_args.hpp"
+
+namespace cmk {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// bounds-checked 16-byte load: lanes whose byte offset lies outside [0, num_records) of the resource get 0
+__device__ f32x4 w6_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+
+constexpr int W6_TR = 3, W6_TC = 10;                   // tiles of 4x4 outputs per workgroup
+constexpr int W6_OH = 4 * W6_TR, W6_OW = 4 * W6_TC;    // 12 x 40 output pixels
+constexpr int W6_HC = W6_OW + 2;                       // 42 halo columns
+constexpr int W6_ITEMS = W6_TR * W6_HC * 2;            // pass-1 items: (tile row, halo column, channel quad) = 252
+constexpr int W6_AP = 48;                              // W image pitches in 16-byte slots: grid row a
+constexpr int W6_TP = 6 * W6_AP + 10;                  //   tile row t: == 10 (mod 16), see w6_slot
+constexpr int W6_QP = W6_TR * W6_TP;                   //   channel quad
+constexpr int W6_WB = 2 * W6_QP;                       // one W buffer = 1788 slots
+constexpr int W6_EX_FLOATS = 4 * 4 * 2 * 8 * 64;       // epilogue exchange: [src wave][dst wave][reg of the round][value][lane] = 64 KiB
+constexpr int W6_LDS_BYTES = (2 * W6_WB * 16 > W6_EX_FLOATS * 4) ? 2 * W6_WB * 16 : W6_EX_FLOATS * 4;   // loop 57,216, exchange 65,536: two workgroups per CU
+static_assert(2 * W6_LDS_BYTES <= LDS_CU, "two workgroups per CU");
+static_assert(W6_ITEMS <= 256, "one pass-1 item per thread");
+
+// W image, in 16-byte slots: entry (channel quad q, tile row t, grid row a, halo column col) lives at
+//   q*QP + t*TP + a*AP + (col & 3)*12 + (col >> 2)
+// A lane of the MFMA side is tile m = 10*t + tc and reads col = 4*tc + j, i.e. slot = const + t*TP + tc (+1 for j >= 4).  A
+// ds_read_b128 is served in groups of 16 lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} per half wave; with TP == 10 (mod 16) the tiles
+// of either group fall on 16 distinct slots modulo 16 (t = 0: tc, t = 1: 10 + tc, t = 2: 4 + tc; lanes 30, 31 carry no tile and read
+// the two slots that are left), whatever a and j are: conflict-free without padding the rows.
+__device__ __forceinline__ int w6_slot(int q, int t, int a, int col) {
+    return q * W6_QP + t * W6_TP + a * W6_AP + (col & 3) * 12 + (col >> 2);
+}
+
+// one half of the 1-D input transform (B^T rows 0-2 or 3-5) on five consecutive samples x0..x4 (= d0..d4 for the first half, d1..d5 for
+// the second):   first:  4x0-5x2+x4, (x4-4x2)+(x3-4x1), (x4-4x2)-(x3-4x1)      second: (x3-x1)+2(x2-x0), (x3-x1)-2(x2-x0), 4x0-5x2+x4
+template <typename T>
+__device__ __forceinline__ void w6_half_first(const T x0, const T x1, const T x2, const T x3, const T x4, T& v0, T& v1, T& v2) {
+    const T p = x4 - 4.0f * x2, q = x3 - 4.0f * x1;
+    v0 = 4.0f * x0 + (x4 - 5.0f * x2);
+    v1 = p + q;
+    v2 = p - q;
+}
+template <typename T>
+__device__ __forceinline__ void w6_half_second(const T x0, const T x1, const T x2, const T x3, const T x4, T& v0, T& v1, T& v2) {
+    const T r = x3 - x1, s = 2.0f * (x2 - x0);
+    v0 = r + s;
+    v1 = r - s;
+    v2 = 4.0f * x0 + (x4 - 5.0f * x2);
+}
+
+// AFF: the producer's GroupNorm+ReLU is applied to the input in pass 1 (FCOS tower convs 2-4 and the predictors)
+template <bool AFF>
+__global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* sW = reinterpret_cast<f32x4*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, li = lane & 31;
+
+    // XCD-aware order, as in the other conv kernels: the grid_y cout tiles of one spatial tile go to the same XCD, back to back
+    const int xq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int bx = (xq / a.grid_y) * 8 + xcd, by = xq % a.grid_y;
+    if (bx >= a.total_tiles) return;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < a.nprob && bx >= a.p[i].tile_begin) pi = i;
+    const ConvProblem& P = a.p[pi];
+    const int H = P.H, W = P.W;
+    const int tile = bx - P.tile_begin;
+    const int tw = tile % P.tiles_w;
+    const int t2 = tile / P.tiles_w;
+    const int th = t2 % P.tiles_h;
+    const int n = t2 / P.tiles_h;
+    const int oh0 = th * W6_OH, ow0 = tw * W6_OW;
+    const int co0 = by * 32;
+    const int nchunks = a.Cin >> 3;
+
+    // ---- pass 1 item of this thread ----------------------------------------------------------------------------------------------
+    const int p_item = min(tid, W6_ITEMS - 1);                     // threads 252..255 repeat the last item (same values, same slots)
+    const int p_q = p_item & 1, p_cc = p_item >> 1;
+    const int p_t = p_cc / W6_HC, p_col = p_cc - p_t * W6_HC;
+    // buffer resource over image n: {base, num_records = bytes of the image, raw dword format}
+    i32x4 rsrc;
+    {
+        const unsigned long long base = (unsigned long long)(P.x + (long)n * H * W * a.x_cs);
+        rsrc.x = __builtin_amdgcn_readfirstlane((int)(base & 0xffffffffull));
+        rsrc.y = __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffull));
+        rsrc.z = __builtin_amdgcn_readfirstlane(H * W * a.x_cs * 4);
+        rsrc.w = 0x00020000;
+    }
+    const int row_bytes = W * a.x_cs * 4;
+    const int ih0 = oh0 - 1 + 4 * p_t, iw = ow0 - 1 + p_col;
+    // byte offset of input row 0 of the item; rows above/below the image are out of the resource's range by themselves, a column
+    // outside the image would alias the neighbouring row, so it is pushed out of range
+    const int voff0 = (iw >= 0 && iw < W) ? (ih0 * W + iw) * a.x_cs * 4 + (a.x_co + p_q * 4) * 4 : (int)0x80000000;
+    unsigned okm = 0;                                              // AFF only: relu(0*s + b) != 0, so padding needs the mask
+    if (AFF) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) okm |= ((iw >= 0 && iw < W && ih0 + i >= 0 && ih0 + i < H) ? 1u : 0u) << i;
+    }
+    const float* aff_s = AFF ? P.in_scale + (long)n * a.Cin + p_q * 4 : nullptr;
+    const float* aff_b = AFF ? P.in_shift + (long)n * a.Cin + p_q * 4 : nullptr;
+    f32x4 d[6];
+    f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
+    auto load_D = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = w6_buffer_load(rsrc, voff0 + i * row_bytes, chunk * 32, 0);
+        if (AFF) {
+            in_sc = *reinterpret_cast<const f32x4*>(aff_s + chunk * 8);
+            in_sh = *reinterpret_cast<const f32x4*>(aff_b + chunk * 8);
+        }
+    };
+    const int p_dst = w6_slot(p_q, p_t, 0, p_col);
+    auto pass1 = [&](f32x4* wbuf) {
+        if (AFF) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                f32x4 v = d[i];
+                const bool k = (okm >> i) & 1u;
+                v.x = fmaxf(v.x * in_sc.x + in_sh.x, 0.f); v.y = fmaxf(v.y * in_sc.y + in_sh.y, 0.f);
+                v.z = fmaxf(v.z * in_sc.z + in_sh.z, 0.f); v.w = fmaxf(v.w * in_sc.w + in_sh.w, 0.f);
+                v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+                d[i] = v;
+            }
+        }
+        f32x4 w0, w1, w2, w3, w4, w5;
+        w6_half_first(d[0], d[1], d[2], d[3], d[4], w0, w1, w2);
+        w6_half_second(d[1], d[2], d[3], d[4], d[5], w3, w4, w5);
+        f32x4* dst = wbuf + p_dst;
+        dst[0 * W6_AP] = w0; dst[1 * W6_AP] = w1; dst[2 * W6_AP] = w2;
+        dst[3 * W6_AP] = w3; dst[4 * W6_AP] = w4; dst[5 * W6_AP] = w5;
+    };
+
+    // ---- MFMA side -------------------------------------------------------------------------------------------------------------
+    // A operand row li = tile m = 10*t + tc (m = 30, 31: no tile; they read initialised-or-not LDS, their accumulator rows are never
+    // stored); lane half hh = channel quad; accumulator register r of lane half hh is tile m = (r & 3) + 8*(r >> 2) + 4*hh, column
+    // li = output channel co0 + li
+    const int rowA = wave, rowB = 4 + (wave >> 1), halfB = wave & 1;
+    const int m_t = li / W6_TC, m_tc = li - m_t * W6_TC;
+    const f32x4* wl = sW + w6_slot(hh, m_t, 0, 4 * m_tc);
+    const f32x4* wA = wl + rowA * W6_AP;
+    const f32x4* wB = wl + rowB * W6_AP;
+    // U image: [chunk][cout tile][wave][9 slots][lane 64][4 floats]; slot k < 6: frequency (rowA, k); k >= 6: (rowB, 3*halfB + k - 6);
+    // lane = 32*hh + li holds channels 8*chunk + 4*hh .. +3 of output channel 32*tile + li
+    const float* u_lane = a.w + ((long)by * 4 + wave) * (9 * 256) + lane * 4;
+    const long u_chunk = (long)a.grid_y * (36 * 256);
+    f32x4 ub[3][3];
+    auto load_U = [&](int step, int buf) {          // step = chunk*3 + s
+        const int c = step / 3, s = step - c * 3;
+        const float* src = u_lane + c * u_chunk + s * (3 * 256);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ub[buf][k] = *reinterpret_cast<const f32x4*>(src + k * 256);
+    };
+    const int total_steps = nchunks * 3;
+
+    // ---- prologue ----------------------------------------------------------------------------------------------------------------
+    load_D(0);
+    load_U(0, 0);
+    load_U(min(1, total_steps - 1), 1);
+    pass1(sW);
+    load_D(min(1, nchunks - 1));
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // ---- main loop: one period per 8-channel chunk ------------------------------------------------------------------------------
+    //   barrier: W(c) complete, everybody is done with W(c-1)
+    //   step 0 (row A, first half); pass 1 of chunk c+1 (in registers since the last period) into the other W buffer; request chunk c+2
+    //   steps 1, 2 (row A second half, row B half)
+    // The wave's 4 channels are transformed and consumed two at a time, which halves the live registers of pass 2.
+    auto xform = [&](const f32x4* wrow, bool second, int h, f32x2& v0, f32x2& v1, f32x2& v2) {
+        const f32x2* w2 = reinterpret_cast<const f32x2*>(wrow) + h;
+        if (!second) {
+            const f32x2 x0 = w2[0 * 2], x1 = w2[12 * 2], x2 = w2[24 * 2], x3 = w2[36 * 2], x4 = w2[1 * 2];
+            w6_half_first(x0, x1, x2, x3, x4, v0, v1, v2);
+        } else {
+            const f32x2 x0 = w2[12 * 2], x1 = w2[24 * 2], x2 = w2[36 * 2], x3 = w2[1 * 2], x4 = w2[13 * 2];
+            w6_half_second(x0, x1, x2, x3, x4, v0, v1, v2);
+        }
+    };
+    auto mm = [&](const f32x2 v0, const f32x2 v1, const f32x2 v2, int h, int sbuf, int abase) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            acc[abase + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[s], ub[sbuf][0][2 * h + s], acc[abase + 0], 0, 0, 0);
+            acc[abase + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s], ub[sbuf][1][2 * h + s], acc[abase + 1], 0, 0, 0);
+            acc[abase + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[s], ub[sbuf][2][2 * h + s], acc[abase + 2], 0, 0, 0);
+        }
+    };
+    auto mfma_step = [&](const f32x4* wrow, bool second, int sbuf, int abase) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x2 v0, v1, v2;
+            xform(wrow, second, h, v0, v1, v2);
+            mm(v0, v1, v2, h, sbuf, abase);
+        }
+    };
+    for (int c = 0; c < nchunks; ++c) {
+        const int wcur = (c & 1) * W6_WB;
+        f32x4* wnext = sW + ((c + 1) & 1) * W6_WB;
+        const int step = c * 3;
+        __syncthreads();
+        load_U(min(step + 2, total_steps - 1), 2);
+        mfma_step(wA + wcur, false, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);            // region fences: with 144 accumulators the scheduler must not stack the regions' registers
+        pass1(wnext);
+        load_D(min(c + 2, nchunks - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        load_U(min(step + 3, total_steps - 1), 0);
+        mfma_step(wA + wcur, true, 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        load_U(min(step + 4, total_steps - 1), 1);
+        // row B: which half is wave-uniform.  Only the transform sits in the branch (kept a branch by the empty asm: if-converted it would
+        // run both halves); MFMAs on both sides of a branch make the allocator keep two copies of the accumulators they touch.
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x2 v0, v1, v2;
+            if (halfB == 0) {
+                asm volatile("" ::: "memory");
+                xform(wB + wcur, false, h, v0, v1, v2);
+            } else {
+                asm volatile("" ::: "memory");
+                xform(wB + wcur, true, h, v0, v1, v2);
+            }
+            mm(v0, v1, v2, h, 2, 6);
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------------
+    // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  Row pass in registers: per accumulator entry the wave's 6 + 3
+    // frequencies become P[rowA][0..3] and the partial P[rowB][0..3] of its half (the two halves add up).  Wave d finishes the tiles of
+    // accumulator registers 4d..4d+3: in round q the other waves send it the 8 values of registers 4d+2q, 4d+2q+1.
+    // scale/shift are requested here: the two exchange rounds cover their latency (loaded inside the store loop they would serialise it)
+    const int co = co0 + li;
+    const bool cvalid = co < a.Cout;
+    const float sc = P.scale[min(co, a.Cout - 1)];
+    const float sh = P.shift[min(co, a.Cout - 1)];
+    __syncthreads();
+    float* ex = smem;
+    const bool do_relu = co < a.relu_upto;
+    float gs = 0.f, gss = 0.f;
+    float* yimg = P.y + (long)n * H * W * a.y_cs + a.y_co + co;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float own[2][8];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 4 * dd + 2 * q + rr;
+                float v[8];
+                {
+                    const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+                    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                    v[0] = m0 + s1 + s2;
+                    v[1] = d1 + 2.0f * d2;
+                    v[2] = s1 + 4.0f * s2;
+                    v[3] = d1 + 8.0f * d2 + m5;
+                    const float n0 = acc[6][r], n1 = acc[7][r], n2 = acc[8][r];
+                    if (halfB == 0) {      // b = 0, 1, 2
+                        const float t1 = n1 + n2, e1 = n1 - n2;
+                        v[4] = n0 + t1; v[5] = e1; v[6] = t1; v[7] = e1;
+                    } else {               // b = 3, 4, 5
+                        const float t2s = n0 + n1, e2 = n0 - n1;
+                        v[4] = t2s; v[5] = 2.0f * e2; v[6] = 4.0f * t2s; v[7] = 8.0f * e2 + n2;
+                    }
+                }
+                if (dd == wave) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) own[rr][k] = v[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ex[((((wave * 4 + dd) * 2 + rr) * 8 + k) << 6) + lane] = v[k];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            // P[a][j]: rows 0..3 from waves 0..3 (values 0..3), row 4 = halves of waves 0, 1, row 5 = halves of waves 2, 3 (values 4..7)
+            float Pm[6][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { Pm[4][j] = 0.f; Pm[5][j] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float v[8];
+                if (s == wave) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = own[rr][k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = ex[((((s * 4 + wave) * 2 + rr) * 8 + k) << 6) + lane];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { Pm[s][j] = v[j]; Pm[4 + (s >> 1)][j] += v[4 + j]; }
+            }
+            // this entry is accumulator register 4*wave + 2q + rr of lane half hh: tile m
+            const int m = 2 * q + rr + 8 * wave + 4 * hh;
+            const int mt = (m * 205) >> 11, mtc = m - mt * W6_TC;         // m / 10 for m < 32
+            const int oh = oh0 + 4 * mt, ow = ow0 + 4 * mtc;
+            const bool tile_ok = cvalid && m < W6_TR * W6_TC;
+            float* yp0 = yimg + ((long)oh * W + ow) * a.y_cs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s1 = Pm[1][j] + Pm[2][j], d1 = Pm[1][j] - Pm[2][j], s2 = Pm[3][j] + Pm[4][j], d2 = Pm[3][j] - Pm[4][j];
+                float y[4];
+                y[0] = Pm[0][j] + s1 + s2;
+                y[1] = d1 + 2.0f * d2;
+                y[2] = s1 + 4.0f * s2;
+                y[3] = d1 + 8.0f * d2 + Pm[5][j];
+                const bool colok = tile_ok && (ow + j < W);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = y[i] * sc + sh;
+                    if (do_relu) v = fmaxf(v, 0.f);
+                    if (colok && (oh + i < H)) {
+                        yp0[((long)i * W + j) * a.y_cs] = v;
+                        gs += v;
+                        gss = fmaf(v, v, gss);
+                    }
+                }
+            }
+        }
+        if (q == 0) __syncthreads();                        // the exchange buffer is reused by round 1
+    }
+    // fused GroupNorm statistics of the NEXT layer's normalisation (fcos.py:182-186): one {sum, sumsq} record per
+    // (spatial tile, wave, group)
+    if (a.gn_ws) {
+        for (int o = 1; o < a.gn_cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
+        gs += __shfl_xor(gs, 32);
+        gss += __shfl_xor(gss, 32);
+        if (cvalid && hh == 0 && (li & (a.gn_cpg - 1)) == 0) {
+            double* o = a.gn_ws + (((long)bx * 4 + wave) * a.gn_groups + co / a.gn_cpg) * 2;
+            o[0] = (double)gs;
+            o[1] = (double)gss;
+        }
+    }
+}
+
+int launch_wino6(ConvArgs& a, hipStream_t st) {
+    static DeviceOnce once;
+    int rc = once.run([]() {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W6_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W6_LDS_BYTES);
+        return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_wino6: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    });
+    if (rc) return rc;
+    int blocks = 0;
+    for (int i = 0; i < a.nprob; ++i) {
+        ConvProblem& p = a.p[i];
+        p.tile_begin = blocks;
+        p.tiles_h = cdiv(p.Ho, W6_OH);
+        p.tiles_w = cdiv(p.Wo, W6_OW);
+        blocks += p.N * p.tiles_h * p.tiles_w;
+    }
+    a.grid_y = cdiv(a.Cout, 32);
+    a.total_tiles = blocks;
+    const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y);
+    if (a.p[0].in_scale)
+        hipLaunchKernelGGL(conv_wino6_kernel<true>, grid, dim3(256), W6_LDS_BYTES, st, a);
+    else
+        hipLaunchKernelGGL(conv_wino6_kernel<false>, grid, dim3(256), W6_LDS_BYTES, st, a);
+    return check_launch("conv_wino6");
+}
+
+}  // namespace cmk
+
+extern "C" int64_t cmk_wino6_packed_floats(int Cout, int Cin) {
+    return (int64_t)((Cin + 7) / 8) * ((Cout + 31) / 32) * 36 * 256;
+}

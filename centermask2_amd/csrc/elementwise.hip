@@ -554,8 +554,8 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const GnTileLeve
     const int g = threadIdx.x % groups, part = threadIdx.x / groups;
     double a = 0.0, b = 0.0;
     if (part < parts) {
-        const long r0 = ((long)L.tile_begin[l] + (long)n * L.tiles[l]) * 2;
-        const int nrec = L.tiles[l] * 2;
+        const long r0 = (long)L.tile_begin[l] + (long)n * L.tiles[l];      // "tiles" here = records per image
+        const int nrec = L.tiles[l];
         double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;      // four independent chains: the loads overlap
         int r = part;
         for (; r + 3 * parts < nrec; r += 4 * parts) {
@@ -596,19 +596,19 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const GnTileLeve
     }
 }
 
-extern "C" int cmk_groupnorm_affine_tiles(const double* ws, const int* Hs, const int* Ws, int nlev, const float* gamma, const float* beta, int N,
+extern "C" int cmk_groupnorm_affine_tiles(const double* ws, const int* Hs, const int* Ws, const int* recs, int nlev, const float* gamma, const float* beta, int N,
                                           int C, int groups, float eps, float* const* out_scale, float* const* out_shift, void* stream) {
-    if (!ws || !Hs || !Ws || !gamma || !beta || !out_scale || !out_shift) return fail(CMK_EINVAL, "groupnorm_affine_tiles: null pointer%s", "");
+    if (!ws || !Hs || !Ws || !recs || !gamma || !beta || !out_scale || !out_shift) return fail(CMK_EINVAL, "groupnorm_affine_tiles: null pointer%s", "");
     if (nlev < 1 || nlev > GN_MAXL || N < 1) return fail(CMK_EINVAL, "groupnorm_affine_tiles: 1..5 levels%s", "");
     if (groups < 1 || groups > 64 || C % groups || C > 4096) return fail(CMK_EINVAL, "groupnorm_affine_tiles: unsupported C/groups%s", "");
     GnTileLevels L;
     int begin = 0;
     for (int l = 0; l < GN_MAXL; ++l) {
         const bool ok = l < nlev;
-        if (ok && (!out_scale[l] || !out_shift[l] || Hs[l] < 1 || Ws[l] < 1)) return fail(CMK_EINVAL, "groupnorm_affine_tiles: bad level%s", "");
+        if (ok && (!out_scale[l] || !out_shift[l] || Hs[l] < 1 || Ws[l] < 1 || recs[l] < 1)) return fail(CMK_EINVAL, "groupnorm_affine_tiles: bad level%s", "");
         L.out_scale[l] = ok ? out_scale[l] : nullptr; L.out_shift[l] = ok ? out_shift[l] : nullptr;
         L.HW[l] = ok ? Hs[l] * Ws[l] : 1;
-        L.tiles[l] = ok ? ((Hs[l] + 7) / 8) * ((Ws[l] + 15) / 16) : 0;    // == cmk_conv_gn_tiles
+        L.tiles[l] = ok ? recs[l] : 0;                                     // cmk_conv_gn_records of the producing conv
         L.tile_begin[l] = begin;
         begin += N * L.tiles[l];
     }

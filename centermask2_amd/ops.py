@@ -103,6 +103,29 @@ def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
     return r
 
 
+_WINO6_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                        dtype=torch.float64)
+
+
+def pack_wino6_weight(w: torch.Tensor) -> torch.Tensor:
+    """Packed U = G g G^T of the Winograd F(4x4,3x3) kernel (cmk_conv_desc.w_wino6; float64 transform, rounded once):
+    [Cin/8][ceil(Cout/32)][wave 4][slot 9][lane = 32*hh + li][4] — slot k < 6: frequency (wave, k); k >= 6: (4 + wave//2, 3*(wave%2) + k - 6);
+    co = tile*32 + li, ci = chunk*8 + 4*hh + j — every operand load of a wave is one contiguous KiB."""
+    lib = _lib.load()
+    cout, cin = w.shape[0], w.shape[1]
+    u = torch.einsum("ik,ockl,jl->ocij", _WINO6_G, w.detach().double().cpu(), _WINO6_G)              # (O, C, 6, 6)
+    cin_pad, nt = (cin + 7) // 8 * 8, (cout + 31) // 32
+    up = torch.zeros((nt * 32, cin_pad, 6, 6), dtype=torch.float64)
+    up[:cout, :cin] = u
+    fa = torch.tensor([[wv if k < 6 else 4 + wv // 2 for k in range(9)] for wv in range(4)])
+    fb = torch.tensor([[k if k < 6 else 3 * (wv % 2) + k - 6 for k in range(9)] for wv in range(4)])
+    sel = up[:, :, fa, fb]                                                                               # (O, C, 4 waves, 9 slots)
+    r = sel.reshape(nt, 32, cin_pad // 8, 2, 4, 4, 9)                                                    # [tile][li][chunk][hh][j][wave][slot]
+    r = r.permute(2, 0, 5, 6, 3, 1, 4).contiguous().float()                                             # [chunk][tile][wave][slot][hh][li][j]
+    assert r.numel() == lib.cmk_wino6_packed_floats(cout, cin)
+    return r.reshape(cin_pad // 8, nt, 4, 9, 64, 4)
+
+
 class PackedConv:
     """Device-resident packed weights + per-channel epilogue (scale, shift) of one conv / linear layer."""
 
@@ -115,6 +138,8 @@ class PackedConv:
         self.stride = stride
         self.w = pack_conv_weight(weight).to(device)
         self.w_wino = pack_wino_weight(weight).to(device) if (self.k == 3 and stride == 1 and self.cin >= 16) else None
+        # F(4x4,3x3) weights: 4x the 3x3 filter bank; packed for every conv that can use them (PACK_WINO6 = False skips it)
+        self.w_wino6 = pack_wino6_weight(weight).to(device) if (PACK_WINO6 and self.k == 3 and stride == 1 and self.cin >= 32) else None
         self.scale = (torch.ones(self.cout) if scale is None else scale.detach().float().cpu()).contiguous().to(device)
         self.shift = (torch.zeros(self.cout) if shift is None else shift.detach().float().cpu()).contiguous().to(device)
 
@@ -132,6 +157,7 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
     d.x, d.x_cs, d.x_co = x.t.data_ptr(), x.cs, x.co
     d.w = pc.w.data_ptr()
     d.w_wino = pc.w_wino.data_ptr() if getattr(pc, "w_wino", None) is not None else None
+    d.w_wino6 = pc.w_wino6.data_ptr() if getattr(pc, "w_wino6", None) is not None else None
     d.scale, d.shift = pc.scale.data_ptr(), pc.shift.data_ptr()
     if res is not None:
         d.res, d.res_cs, d.res_co = res.t.data_ptr(), res.cs, res.co
@@ -156,7 +182,9 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
 
 
 # ---- tile-variant autotuning (host side; the library itself stays stateless) -----------------------------------
+PACK_WINO6 = True         # pack the F(4x4,3x3) weights too (4x the filter bank per 3x3 stride-1 conv)
 ALLOW_WINOGRAD = True     # let the tuner pick the Winograd F(2x2,3x3) kernel where it is faster (fp32, differs by rounding only)
+FORCE_VARIANT = None      # (wm, sc, wn[, splitk]) for every conv launched through the wrappers below (tests, A/B tools); None = table/tuner/default
 AUTOTUNE = False          # when True, the first call of every distinct conv problem times the variant menu (needs an idle, non-capturing stream)
 _TUNED = {}               # problem key -> (wm, sc, wn)
 
@@ -194,7 +222,7 @@ def _variant_on_menu(tv) -> bool:
     """(wm, sc, wn[, splitk]) names a kernel this library has (older tables may carry variants that were removed since)."""
     wm, sc, wn = tv[:3]
     sk = tv[3] if len(tv) > 3 else 1
-    return (wm in (1, 2, 5, 7) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
+    return (wm in (1, 2, 5, 6, 7) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
 
 
 def load_tuned(path: str) -> int:
@@ -251,6 +279,7 @@ def _tune(descs, n, key) -> None:
         cands += [(7, 32, wn, sk) for wn in (1, 2, 4) for sk in sks]      # gather form
     if ALLOW_WINOGRAD:
         cands += [(5, 16, 2, 1)]                  # fused Winograd F(2x2,3x3)
+        cands += [(6, 16, 1, 1)]                  # fused Winograd F(4x4,3x3) (rejected by the library where it does not apply)
     for tv in cands:
         ws = _set_variant(descs, n, tv)
         if run() != 0:
@@ -279,6 +308,8 @@ def _default_variant(d):
 
 
 def _apply_tuning(descs, n, key):
+    if FORCE_VARIANT is not None:
+        return _set_variant(descs, n, FORCE_VARIANT)
     tv = _TUNED.get(key)
     if tv is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing():
         _tune(descs, n, key)
@@ -350,25 +381,26 @@ def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Te
 
     d0 = descs[0]
     cpg = pc.cout // groups if groups > 0 and pc.cout % groups == 0 else 0
-    wino = d0.tune_wm == 5 or ((d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0) and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
+    wino = d0.tune_wm in (5, 6) or ((d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0) and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
+    gn_form = 6 if d0.tune_wm == 6 else 5
     fused = wino and 0 < cpg <= 32 and (cpg & (cpg - 1)) == 0 and all(x.t.shape[0] == xs[0].t.shape[0] for x in xs)
     if not fused:
         launch()
         del ws
         return ys, groupnorm_affine_multi([y.t for y in ys], gamma, beta, groups, eps)
     nimg, dev = xs[0].t.shape[0], xs[0].t.device
-    tiles = sum(nimg * lib.cmk_conv_gn_tiles(y.t.shape[1], y.t.shape[2]) for y in ys)
-    gws = torch.empty((tiles, 2, groups, 2), dtype=torch.float64, device=dev)
+    recs_l = [lib.cmk_conv_gn_records(y.t.shape[1], y.t.shape[2], gn_form) for y in ys]
+    gws = torch.empty((nimg * sum(recs_l), groups, 2), dtype=torch.float64, device=dev)
     for i in range(n):
         descs[i].gn_ws, descs[i].gn_groups = gws.data_ptr(), groups
     launch()
     out = [(torch.empty((nimg, pc.cout), dtype=torch.float32, device=dev), torch.empty((nimg, pc.cout), dtype=torch.float32, device=dev)) for _ in ys]
-    hs, wss = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+    hs, wss, recs = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
     ps, pb = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
     for i, y in enumerate(ys):
-        hs[i], wss[i] = y.t.shape[1], y.t.shape[2]
+        hs[i], wss[i], recs[i] = y.t.shape[1], y.t.shape[2], recs_l[i]
         ps[i], pb[i] = out[i][0].data_ptr(), out[i][1].data_ptr()
-    check(lib.cmk_groupnorm_affine_tiles(gws.data_ptr(), hs, wss, n, gamma.data_ptr(), beta.data_ptr(), nimg, pc.cout, groups, eps, ps, pb,
+    check(lib.cmk_groupnorm_affine_tiles(gws.data_ptr(), hs, wss, recs, n, gamma.data_ptr(), beta.data_ptr(), nimg, pc.cout, groups, eps, ps, pb,
                                          _stream()), "cmk_groupnorm_affine_tiles")
     del ws
     return ys, out
@@ -652,6 +684,8 @@ def _kernel_name(taps, stride, tv, aff=False) -> str:
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
     if tv[0] == 5:
         return "conv_wino4r_kernel<{}>".format("true" if aff else "false")
+    if tv[0] == 6:
+        return "conv_wino6_kernel<{}>".format("true" if aff else "false")
     wm, sc, wn = tv[:3]
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)

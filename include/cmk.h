@@ -9,7 +9,9 @@
  *   - activations are NHWC float32; a tensor "view" is (pointer, channel stride `cs`, channel offset `co`), so a
  *     conv can write straight into a slice of an OSA concat buffer (vovnet.py:324 never materialises);
  *   - returns 0, or a negative CMK_E* code; cmk_last_error() gives the message (thread-local); nothing throws;
- *   - stateless and re-entrant: one process per GPU each loads its own copy.
+ *   - no state beyond one-time, per-device kernel attributes (set on the first launch on each device, idempotent); one process
+ *     per GPU each loads its own copy.  Launches go to the CURRENT device's stream the caller passes: the caller selects the
+ *     device (hipSetDevice / torch.cuda.device) that owns the pointers before calling.
  */
 #ifndef CMK_H
 #define CMK_H
@@ -22,7 +24,7 @@ extern "C" {
 #define CMK_EINVAL (-1)   /* bad argument / unsupported shape */
 #define CMK_ELAUNCH (-2)  /* HIP launch error */
 
-int cmk_version(void);                 /* ABI version, currently 1 */
+int cmk_version(void);                 /* ABI version, currently 2 (2: cmk_conv_desc.w_wino6, cmk_groupnorm_affine_tiles takes record counts) */
 const char* cmk_arch(void);            /* "gfx950" */
 const char* cmk_last_error(void);
 
@@ -72,8 +74,16 @@ typedef struct {
      * tune_wm == 5, relu_upto == 0 and Cout/gn_groups a power of two <= 32.  The kernel writes {sum, sum of squares} per
      * (spatial tile of 8x16 outputs, row parity, group) to gn_ws as doubles: record index ((tile*2 + parity)*gn_groups + group),
      * tiles numbered image-major per problem (for _multi: problems back to back) with cmk_conv_gn_tiles(H, W) tiles per image;
-     * cmk_groupnorm_affine_tiles turns them into the per-(image, channel) scale/shift.  NULL = off. */
+     * cmk_groupnorm_affine_tiles turns them into the per-(image, channel) scale/shift.  NULL = off.
+     * With tune_wm == 6 the records are per (spatial tile of 12x40 outputs, wave 0..3, group): index ((tile*4 + wave)*gn_groups + group);
+     * cmk_conv_gn_records(H, W, tune_wm) gives the records per image of either form. */
     double* gn_ws; int gn_groups;
+    /* tune_wm == 6 selects the fused Winograd F(4x4,3x3) kernel (conv_wino6.hip; 3x3 stride 1, no residual, Cin % 8 == 0): 36 multiplies
+     * per 4x4 outputs, 1.78x fewer than F(2x2,3x3); fp32 throughout, error ~1.6x the 2x2 form's (tools/wino_numerics.py).  Needs
+     * U = G g G^T (6x6 per filter, points 0, +-1, +-2, inf), cmk_wino6_packed_floats floats packed
+     * [Cin/8][ceil(Cout/32)][wave 4][slot 9][lane 64][4 floats]: slot k < 6 is frequency (row = wave, column = k), slot k >= 6 is
+     * (row = 4 + wave/2, column = 3*(wave%2) + k - 6); output channel = tile*32 + (lane & 31), input channel = chunk*8 + 4*(lane >> 5) + j. */
+    const float* w_wino6;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
 /* Same conv applied to up to 5 inputs of different H x W in ONE launch (the FCOS towers/predictors share their weights
@@ -84,8 +94,11 @@ int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* stream);
 int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize);
 int cmk_conv_cout_pad(int Cout);
 int64_t cmk_wino_packed_floats(int Cout, int Cin);
+int64_t cmk_wino6_packed_floats(int Cout, int Cin);
 /* spatial tiles per image of the fused-statistics conv (8 x 16 outputs each) */
 int cmk_conv_gn_tiles(int H, int W);
+/* {sum, sumsq} records per image written through cmk_conv_desc.gn_ws by the Winograd kernel tune_wm (5 or 6) on an H x W map */
+int cmk_conv_gn_records(int H, int W, int tune_wm);
 
 /* ---- depth-wise 3x3, pad 1, stride 1|2, no bias / norm / activation (vovnet.py:110-119 'dw_conv3x3', the dw half of the
  * depth-wise VoVNet bodies V-19-slim-dw-eSE / V-19-dw-eSE vovnet.py:30-48).  x, y are NHWC channel-slice views
@@ -126,7 +139,8 @@ int cmk_groupnorm_affine_multi(const float* const* xs, const int* HWs, int nlev,
                                void* stream);
 /* Second half of the fused form: the statistics were written by the conv itself (cmk_conv_desc.gn_ws, all levels of one
  * cmk_conv2d_nhwc[_multi] call, N images each); this turns them into the same per-(image, channel) scale/shift. */
-int cmk_groupnorm_affine_tiles(const double* ws, const int* Hs, const int* Ws, int nlev, const float* gamma, const float* beta,
+/* recs[l] = cmk_conv_gn_records(Hs[l], Ws[l], tune_wm of the producing conv): records per image of level l */
+int cmk_groupnorm_affine_tiles(const double* ws, const int* Hs, const int* Ws, const int* recs, int nlev, const float* gamma, const float* beta,
                                int N, int C, int groups, float eps, float* const* out_scale, float* const* out_shift, void* stream);
 
 /* ---- FCOS candidate selection + box decode (fcos_outputs.py:396-466) ------------------------------------------ */

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                      # loads on CPU; no compute call is made here
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cmk_version() == 1 and lib.cmk_arch() == b"gfx950"
+    assert lib.cmk_version() == 2 and lib.cmk_arch() == b"gfx950"
     assert lib.cmk_conv_cout_pad(80) == 96 and lib.cmk_conv_cout_pad(160) == 160 and lib.cmk_conv_cout_pad(1024) == 1024
     assert lib.cmk_conv_packed_floats(256, 257, 3) == 9 * 17 * 256 * 16
 
@@ -119,7 +119,7 @@ def test_shipped_variant_tables_name_existing_kernels(tmp_path):
         assert all(ops._key_to_str(ops._str_to_key(k)) == k for k in table)
     stale = tmp_path / "stale.json"
     key = next(iter(json.load(open(tables[0]))))
-    stale.write_text(json.dumps({key: [6, 16, 2]}))          # a Winograd form that was removed
+    stale.write_text(json.dumps({key: [4, 16, 2]}))          # a Winograd form that was removed
     saved = dict(ops._TUNED)
     try:
         ops._TUNED.clear()

@@ -170,24 +170,98 @@ def test_conv_multi_level_launch(dev):
         _close(y.nchw(), ref)
 
 
-@pytest.mark.parametrize("variant", ["2x16", "2x32", "1x16", "1x32"])
-def test_conv_tile_variants_forced(dev, variant):
-    """Every (WM, sub-tile shape) variant of the 3x3 kernel gives the same result (the cost model only picks among them).
-    The override is read once per process, so each variant runs in a fresh interpreter."""
-    import os, subprocess, sys
-    code = (
-        "import sys, torch, torch.nn.functional as F; sys.path.insert(0, %r)\n"
-        "from centermask2_amd import ops\n"
-        "g = torch.Generator().manual_seed(3)\n"
-        "for (n,h,w,cin,cout) in [(2,37,45,64,128),(1,20,70,32,96),(1,9,33,48,160)]:\n"
-        "    x = torch.randn((n,cin,h,w), generator=g); wt = torch.randn((cout,cin,3,3), generator=g)*0.05\n"
-        "    ref = F.relu(F.conv2d(x, wt, None, padding=1))\n"
-        "    y = ops.conv_out(ops.as_view(x.cuda()), ops.PackedConv(wt, None, None, 'cuda'), relu=True)\n"
-        "    torch.cuda.synchronize()\n"
-        "    err = (y.nchw().cpu()-ref).abs().max().item(); assert err < 2e-4*max(1,ref.abs().max().item()), err\n"
-        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CMK_CONV_VARIANT=variant), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+def _run_variant(dev, x, wt, scale, shift, tv, stride=1, relu=True):
+    """One conv through the C ABI with the tile variant written into the descriptor (cmk_conv_desc.tune_*), as the tuner does."""
+    import ctypes
+    from centermask2_amd import _lib
+    pc = ops.PackedConv(wt, scale, shift, dev, stride=stride)
+    xv = ops.as_view(x.to(dev))
+    n, _, h, w = x.shape
+    ho, wo = (h, w) if stride == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
+    y = View(torch.full((n, ho, wo, wt.shape[0]), -5.0, device=dev))
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], xv, pc, y, relu, None, None, False, False)
+    ws = ops._set_variant(d, 1, tv)
+    rc = _lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream())
+    torch.cuda.synchronize()
+    del ws
+    return rc, y
+
+
+DIRECT_VARIANT_SHAPES = [(2, 37, 45, 64, 128), (1, 20, 70, 32, 96), (1, 9, 33, 48, 160), (1, 17, 23, 64, 192), (1, 11, 19, 32, 224)]
+
+
+@pytest.mark.parametrize("wm,sc", [(1, 16), (1, 32), (2, 16), (2, 32)])
+def test_conv_direct_tile_variants(dev, wm, sc):
+    """Every (WM, sub-tile, WN) instantiation of the direct 3x3 stride-1 kernel that the library admits for a shape, driven through
+    the real knob (the descriptor's tune_* fields).  The start-up tuner may pick any of them, so each must be right by itself."""
+    ran = 0
+    for (n, h, w, cin, cout) in DIRECT_VARIANT_SHAPES:
+        x = _rand((n, cin, h, w), 31)
+        wt = _rand((cout, cin, 3, 3), 32, (2.0 / (cin * 9)) ** 0.5)
+        scale = torch.rand(cout, generator=torch.Generator().manual_seed(33)) + 0.5
+        shift = _rand((cout,), 34, 0.1)
+        ref = F.relu(F.conv2d(x, wt, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        for wn in range(1, 8):
+            rc, y = _run_variant(dev, x, wt, scale, shift, (wm, sc, wn))
+            if rc != 0:
+                continue                  # not on the menu for this Cout (WN must divide the padded Cout; WM 2 needs WN <= 4)
+            _close(y.nchw(), ref)
+            ran += 1
+    assert ran >= 6, ran
+
+
+def test_conv_stride2_and_1x1_variants(dev):
+    for (n, h, w, cin, cout, k, stride, tvs) in [(1, 21, 35, 64, 128, 3, 2, [(1, 16, 1), (1, 16, 2), (1, 16, 4)]),
+                                                 (2, 13, 19, 96, 256, 1, 1, [(1, 32, 1), (1, 32, 2), (1, 32, 4), (2, 32, 2), (2, 32, 4)])]:
+        x = _rand((n, cin, h, w), 35)
+        wt = _rand((cout, cin, k, k), 36, (2.0 / (cin * k * k)) ** 0.5)
+        ref = F.relu(F.conv2d(x, wt, None, stride=stride, padding=k // 2))
+        for tv in tvs:
+            rc, y = _run_variant(dev, x, wt, None, None, tv, stride=stride)
+            assert rc == 0, tv
+            _close(y.nchw(), ref)
+
+
+WINO6_CASES = [(2, 37, 45, 64, 128), (1, 16, 16, 256, 256), (1, 25, 40, 224, 224), (2, 14, 14, 256, 80), (1, 100, 160, 32, 5),
+               (1, 12, 40, 128, 32), (1, 13, 41, 40, 33), (3, 5, 3, 32, 64), (1, 50, 80, 192, 192)]
+
+
+@pytest.mark.parametrize("case", WINO6_CASES)
+def test_conv_winograd6_variant(dev, case):
+    """Fused Winograd F(4x4,3x3) kernel (tune_wm 6) against torch: exact tiles, ragged edges in both directions, maps smaller than a
+    tile, Cout not a multiple of 32, Cin a multiple of 8 only.  fp32 rounding differences only (tolerance as for every conv here)."""
+    n, h, w, cin, cout = case
+    x = _rand((n, cin, h, w), 81)
+    wt = _rand((cout, cin, 3, 3), 82, (2.0 / (cin * 9)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(83)) + 0.5
+    shift = _rand((cout,), 84, 0.1)
+    ref = F.relu(F.conv2d(x, wt, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    rc, y = _run_variant(dev, x, wt, scale, shift, (6, 16, 1))
+    assert rc == 0
+    _close(y.nchw(), ref)
+    rc, y = _run_variant(dev, x, wt, scale, shift, (6, 16, 1))          # a second, warm launch agrees bit for bit with the first
+    assert rc == 0
+
+
+def test_conv_winograd6_channel_views(dev):
+    """tune_wm 6 reading a channel slice of a wider buffer (an OSA concat buffer) and writing into a slice of another; partial ReLU."""
+    import ctypes
+    from centermask2_amd import _lib
+    n, h, w, cin, cout = 2, 23, 47, 64, 48
+    big = _rand((n, h, w, 160), 5).to(dev)
+    wt = _rand((cout, cin, 3, 3), 6, 0.06)
+    out = torch.full((n, h, w, 96), -7.0, device=dev)
+    pc = ops.PackedConv(wt, None, _rand((cout,), 8, 0.1), dev)
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], View(big, 32, cin), pc, View(out, 16, cout), False, 4, None, False, False)
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 6, 16, 1
+    _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "wino6 views")
+    torch.cuda.synchronize()
+    ref = F.conv2d(big[..., 32:96].permute(0, 3, 1, 2).cpu(), wt, pc.shift.cpu(), padding=1)
+    ref[:, :4] = F.relu(ref[:, :4])
+    _close(out[..., 16:64].permute(0, 3, 1, 2), ref)
+    assert float(out[..., :16].max()) == -7.0 and float(out[..., 64:].min()) == -7.0   # neighbours untouched
 
 
 @pytest.mark.parametrize("case", [(2, 37, 45, 64, 128), (1, 16, 16, 256, 256), (1, 25, 40, 224, 224), (2, 14, 14, 256, 80), (1, 100, 160, 32, 5)])
@@ -268,7 +342,7 @@ def test_conv_split_k_rejects_bad_requests(dev, cmk_lib):
     del ws
 
 
-@pytest.mark.parametrize("variant", [(0, 0, 0), (5, 16, 2), (1, 16, 1)])
+@pytest.mark.parametrize("variant", [(0, 0, 0), (5, 16, 2), (6, 16, 1), (1, 16, 1)])
 def test_conv_fused_groupnorm_relu_input(dev, variant):
     """conv(relu(GroupNorm(x))) with the GN apply fused into the conv's input staging (direct kernels and Winograd form 6)."""
     import ctypes
@@ -294,9 +368,11 @@ def test_conv_fused_groupnorm_relu_input(dev, variant):
     assert _lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
 
 
+@pytest.mark.parametrize("form", [5, 6])
 @pytest.mark.parametrize("cout,groups", [(256, 32), (64, 32), (96, 3)])
-def test_conv_with_fused_groupnorm_statistics(dev, cout, groups):
-    """The Winograd epilogue's {sum, sumsq} records -> the same per-(image, channel) affine as a pass over the output."""
+def test_conv_with_fused_groupnorm_statistics(dev, cout, groups, form, monkeypatch):
+    """The Winograd epilogues' {sum, sumsq} records -> the same per-(image, channel) affine as a pass over the output."""
+    monkeypatch.setattr(ops, "FORCE_VARIANT", (form, 16, 2 if form == 5 else 1))
     g = torch.Generator().manual_seed(21)
     shapes = [(2, 20, 36), (2, 9, 17), (2, 5, 3)]
     cin = 64
