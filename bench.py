@@ -26,6 +26,7 @@ import torch.distributed as dist
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
+PROFILE_ROUND = "r02"            # prefix of the PMC summaries under profiles/ this bench quotes
 
 
 def build(conv_body, device):
@@ -49,7 +50,12 @@ def pack_results(out):
 
 
 def roofline_leg(model, x, sizes):
-    """One instrumented step: HIP events (torch's current stream == the launch stream) around every conv launch."""
+    """One instrumented step: HIP events (torch's current stream == the launch stream) around every conv launch.
+    `achieved`/`frac` price the dominant kernel on the FLOPs the matrix pipe EXECUTES (Winograd-domain multiplies, tile padding
+    included) against the fp32 MFMA peak, so frac <= 1; the direct-convolution (algorithmic) rate SURVEY §8(d) defines is reported
+    beside it as alg_equiv_TFLOPs.  MFMA-busy and HBM traffic come from separate rocprofv3 --pmc passes of this same command
+    (a process cannot read the PMCs of its own launches) kept under profiles/, stamped with the hash of the kernel sources:
+    a summary of an older kernel is reported as null, never quoted."""
     from centermask2_amd import ops
     ops.PROFILE = []
     with torch.no_grad():
@@ -57,35 +63,51 @@ def roofline_leg(model, x, sizes):
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
     agg = {}
-    for key, fl, by, e0, e1, shape in prof:
-        a = agg.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+    for key, fl, by, e0, e1, shape, ex in prof:
+        a = agg.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, exec=0.0))
         a["ms"] += e0.elapsed_time(e1)
         a["flops"] += fl
         a["bytes"] += by
+        a["exec"] += ex
         a["launches"] += 1
     dom = max(agg, key=lambda k: agg[k]["ms"])
     d = agg[dom]
     total_ms = sum(a["ms"] for a in agg.values())
+    khash = ops.kernel_source_hash()
     roof = {
-        "bound": "mfma", "kernel": dom, "achieved": round(d["flops"] / d["ms"] / 1e9, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(d["flops"] / d["ms"] / 1e9 / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+        "bound": "mfma", "kernel": dom, "achieved": round(d["exec"] / d["ms"] / 1e9, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(d["exec"] / d["ms"] / 1e9 / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None, "mfma_busy": None,
+        "definition": "achieved = executed MFMA FLOPs (Winograd-domain, tile padding included) / HIP-event time of the kernel's launches",
+        "alg_equiv_TFLOPs": round(d["flops"] / d["ms"] / 1e9, 2),
         "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-        "alg_flops_per_launch": round(d["flops"] / d["launches"] / 1e9, 3), "alg_GBps": round(d["bytes"] / d["ms"] / 1e6, 1),
-        "hbm_frac": round(d["bytes"] / d["ms"] / 1e6 / PEAK_HBM_GBS, 4),
-        "all_convs": {"ms_per_step": round(total_ms, 3), "TFLOP/s": round(sum(a["flops"] for a in agg.values()) / total_ms / 1e9, 2),
+        "exec_flops_per_launch": round(d["exec"] / d["launches"] / 1e9, 3), "alg_flops_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+        "alg_bytes_per_launch": round(d["bytes"] / d["launches"]), "alg_GBps": round(d["bytes"] / d["ms"] / 1e6, 1),
+        "hbm_frac": round(d["bytes"] / d["ms"] / 1e6 / PEAK_HBM_GBS, 4), "kernel_source_hash": khash,
+        "all_convs": {"ms_per_step": round(total_ms, 3), "exec_TFLOP/s": round(sum(a["exec"] for a in agg.values()) / total_ms / 1e9, 2),
+                      "alg_equiv_TFLOPs": round(sum(a["flops"] for a in agg.values()) / total_ms / 1e9, 2),
+                      "frac": round(sum(a["exec"] for a in agg.values()) / total_ms / 1e9 / PEAK_F32_MATRIX_TFLOPS, 4),
                       "alg_GBps": round(sum(a["bytes"] for a in agg.values()) / total_ms / 1e6, 1)},
-        "per_kernel": {k: {"ms": round(a["ms"], 3), "TFLOP/s": round(a["flops"] / a["ms"] / 1e9, 1), "launches": a["launches"]}
+        "per_kernel": {k: {"ms": round(a["ms"], 3), "exec_TFLOP/s": round(a["exec"] / a["ms"] / 1e9, 1), "frac": round(a["exec"] / a["ms"] / 1e9 / PEAK_F32_MATRIX_TFLOPS, 3),
+                           "alg_equiv_TFLOPs": round(a["flops"] / a["ms"] / 1e9, 1), "launches": a["launches"]}
                        for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
     }
-    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (a process cannot
-    # read the PMCs of its own launches); tools/pmc_traffic.py writes them, with the gfx950 corrections, to profiles/.
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath):
-        t = json.load(open(tpath)).get(dom)
-        if t:
-            roof["traffic"] = round(t["hbm_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-            roof["alg_bytes_per_launch"] = round(d["bytes"] / d["launches"])
+    for fname, field in (("pmc_traffic.json", "traffic"), ("pmc_mfma.json", "mfma_busy")):
+        path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_" + fname)
+        if not os.path.exists(path):
+            continue
+        t = json.load(open(path))
+        if t.get("_kernel_source_hash") != khash:
+            roof[field + "_source"] = "profiles/{}_{} is of kernel sources {} (now {}): not quoted".format(PROFILE_ROUND, fname, t.get("_kernel_source_hash"), khash)
+            continue
+        e = t.get(dom)
+        if not e:
+            continue
+        if field == "traffic":
+            roof["traffic"] = round(e["hbm_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/{}_{} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)".format(PROFILE_ROUND, fname)
+        else:
+            roof["mfma_busy"] = round(e["mfma_busy_frac"], 4)
+            roof["mfma_busy_source"] = "profiles/{}_{} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE; busy cycles / (4 SIMDs x busy CU cycles))".format(PROFILE_ROUND, fname)
     return roof
 
 

@@ -928,6 +928,7 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
             if (rc) return rc;
         }
         a.w = d->w_wino6;
+        a.ws = d->splitk_ws;          // instrumented builds (W6_TRACE) only: a stamp buffer; unused otherwise
         return launch_wino6(a, st);
     }
     a.ksplit = d->splitk > 1 ? d->splitk : 1;

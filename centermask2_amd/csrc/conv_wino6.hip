@@ -32,6 +32,12 @@
 // sam.py:58-70, maskiou_head.py:81-88).
 #include "conv_args.hpp"
 
+#ifndef W6_NOFENCE
+#define W6_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define W6_FENCE
+#endif
+
 namespace cmk {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -188,12 +194,36 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     };
     const int total_steps = nchunks * 3;
 
+#ifdef W6_TRACE
+    // instrumented build (tools/ab/trace_wino6.py): lane 0 of every wave of every 16th workgroup stamps the shader clock into a.ws
+    unsigned long long* trc = (a.ws && (blockIdx.x & 15) == 0 && lane == 0) ? reinterpret_cast<unsigned long long*>(a.ws) + ((blockIdx.x >> 4) * 4 + wave) * 64 : nullptr;
+    int trn = 0;
+#define W6_STAMP() do { if (trc) { trc[trn] = __builtin_readcyclecounter(); } ++trn; } while (0)
+    if (trc) trc[63] = __builtin_amdgcn_s_memrealtime();
+#else
+#define W6_STAMP() do { } while (0)
+#endif
+    W6_STAMP();                                       // 0: start
     // ---- prologue ----------------------------------------------------------------------------------------------------------------
+    // the halos of chunks 0 and 1 and the first weights are requested together: one memory round trip before the first MFMA
     load_D(0);
+    f32x4 d_first[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d_first[i] = d[i];
+    f32x4 sc_first = in_sc, sh_first = in_sh;
+    load_D(min(1, nchunks - 1));
     load_U(0, 0);
     load_U(min(1, total_steps - 1), 1);
-    pass1(sW);
-    load_D(min(1, nchunks - 1));
+    {
+        f32x4 d_keep[6], sc_keep = in_sc, sh_keep = in_sh;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { d_keep[i] = d[i]; d[i] = d_first[i]; }
+        in_sc = sc_first; in_sh = sh_first;
+        pass1(sW);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = d_keep[i];
+        in_sc = sc_keep; in_sh = sh_keep;
+    }
 
     f32x16 acc[9];
 #pragma unroll
@@ -206,15 +236,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     //   step 0 (row A, first half); pass 1 of chunk c+1 (in registers since the last period) into the other W buffer; request chunk c+2
     //   steps 1, 2 (row A second half, row B half)
     // The wave's 4 channels are transformed and consumed two at a time, which halves the live registers of pass 2.
-    auto xform = [&](const f32x4* wrow, bool second, int h, f32x2& v0, f32x2& v1, f32x2& v2) {
+    struct X5 { f32x2 x0, x1, x2, x3, x4; };
+    // the five W samples one half of a frequency row needs, for channel pair h of the lane's quad: first half = columns 0..4 of the
+    // tile's six, second half = columns 1..5 (slot offsets of w6_slot: +12 per column, column 4 -> +1, column 5 -> +13)
+    auto rd = [&](const f32x4* wrow, bool second, int h) {
         const f32x2* w2 = reinterpret_cast<const f32x2*>(wrow) + h;
-        if (!second) {
-            const f32x2 x0 = w2[0 * 2], x1 = w2[12 * 2], x2 = w2[24 * 2], x3 = w2[36 * 2], x4 = w2[1 * 2];
-            w6_half_first(x0, x1, x2, x3, x4, v0, v1, v2);
-        } else {
-            const f32x2 x0 = w2[12 * 2], x1 = w2[24 * 2], x2 = w2[36 * 2], x3 = w2[1 * 2], x4 = w2[13 * 2];
-            w6_half_second(x0, x1, x2, x3, x4, v0, v1, v2);
-        }
+        X5 x;
+        if (!second) { x.x0 = w2[0 * 2]; x.x1 = w2[12 * 2]; x.x2 = w2[24 * 2]; x.x3 = w2[36 * 2]; x.x4 = w2[1 * 2]; }
+        else         { x.x0 = w2[12 * 2]; x.x1 = w2[24 * 2]; x.x2 = w2[36 * 2]; x.x3 = w2[1 * 2]; x.x4 = w2[13 * 2]; }
+        return x;
+    };
+    auto rdB = [&](const f32x4* wrow, int h) {       // row B: which half is wave-uniform; kept a branch (the empty asm) so that only one runs
+        X5 x;
+        if (halfB == 0) { asm volatile("" ::: "memory"); x = rd(wrow, false, h); }
+        else            { asm volatile("" ::: "memory"); x = rd(wrow, true, h); }
+        return x;
     };
     auto mm = [&](const f32x2 v0, const f32x2 v1, const f32x2 v2, int h, int sbuf, int abase) {
 #pragma unroll
@@ -224,43 +260,49 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
             acc[abase + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[s], ub[sbuf][2][2 * h + s], acc[abase + 2], 0, 0, 0);
         }
     };
-    auto mfma_step = [&](const f32x4* wrow, bool second, int sbuf, int abase) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x2 v0, v1, v2;
-            xform(wrow, second, h, v0, v1, v2);
-            mm(v0, v1, v2, h, sbuf, abase);
-        }
+    // one half-step = 6 MFMAs: transform the samples read during the previous half-step, issue the MFMAs
+    auto half_step = [&](const X5& x, bool second, int h, int sbuf, int abase) {
+        f32x2 v0, v1, v2;
+        if (!second) w6_half_first(x.x0, x.x1, x.x2, x.x3, x.x4, v0, v1, v2);
+        else w6_half_second(x.x0, x.x1, x.x2, x.x3, x.x4, v0, v1, v2);
+        mm(v0, v1, v2, h, sbuf, abase);
     };
+    auto half_stepB = [&](const X5& x, int h) {      // MFMAs stay outside the branch: on both sides of one the allocator keeps two
+        f32x2 v0, v1, v2;                           // copies of the accumulators they touch
+        if (halfB == 0) { asm volatile("" ::: "memory"); w6_half_first(x.x0, x.x1, x.x2, x.x3, x.x4, v0, v1, v2); }
+        else            { asm volatile("" ::: "memory"); w6_half_second(x.x0, x.x1, x.x2, x.x3, x.x4, v0, v1, v2); }
+        mm(v0, v1, v2, h, 2, 6);
+    };
+    W6_STAMP();                                       // 1: prologue done
     for (int c = 0; c < nchunks; ++c) {
         const int wcur = (c & 1) * W6_WB;
         f32x4* wnext = sW + ((c + 1) & 1) * W6_WB;
         const int step = c * 3;
         __syncthreads();
+#ifdef W6_TRACE
+        if (c < 40) W6_STAMP();                       // 2 + c: period c entered
+#endif
+        // the LDS reads of half-step k+1 are issued in front of the MFMAs of half-step k: their latency hides under the 6 MFMAs
         load_U(min(step + 2, total_steps - 1), 2);
-        mfma_step(wA + wcur, false, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);            // region fences: with 144 accumulators the scheduler must not stack the regions' registers
+        X5 xa = rd(wA + wcur, false, 0);
+        X5 xb = rd(wA + wcur, false, 1);
+        half_step(xa, false, 0, 0, 0);
+        xa = rd(wA + wcur, true, 0);
+        half_step(xb, false, 1, 0, 0);
+        W6_FENCE;
         pass1(wnext);
         load_D(min(c + 2, nchunks - 1));
-        __builtin_amdgcn_sched_barrier(0);
+        W6_FENCE;
         load_U(min(step + 3, total_steps - 1), 0);
-        mfma_step(wA + wcur, true, 1, 3);
-        __builtin_amdgcn_sched_barrier(0);
+        xb = rd(wA + wcur, true, 1);
+        half_step(xa, true, 0, 1, 3);
+        xa = rdB(wB + wcur, 0);
+        half_step(xb, true, 1, 1, 3);
+        W6_FENCE;
         load_U(min(step + 4, total_steps - 1), 1);
-        // row B: which half is wave-uniform.  Only the transform sits in the branch (kept a branch by the empty asm: if-converted it would
-        // run both halves); MFMAs on both sides of a branch make the allocator keep two copies of the accumulators they touch.
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x2 v0, v1, v2;
-            if (halfB == 0) {
-                asm volatile("" ::: "memory");
-                xform(wB + wcur, false, h, v0, v1, v2);
-            } else {
-                asm volatile("" ::: "memory");
-                xform(wB + wcur, true, h, v0, v1, v2);
-            }
-            mm(v0, v1, v2, h, 2, 6);
-        }
+        xb = rdB(wB + wcur, 1);
+        half_stepB(xa, 0);
+        half_stepB(xb, 1);
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------------------
@@ -270,9 +312,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     // scale/shift are requested here: the two exchange rounds cover their latency (loaded inside the store loop they would serialise it)
     const int co = co0 + li;
     const bool cvalid = co < a.Cout;
-    const float sc = P.scale[min(co, a.Cout - 1)];
-    const float sh = P.shift[min(co, a.Cout - 1)];
+    float sc = P.scale[min(co, a.Cout - 1)];
+    float sh = P.shift[min(co, a.Cout - 1)];
+#ifdef W6_TRACE
+    trn = 42;
+#endif
+    W6_STAMP();                                       // 42: loop done (own MFMAs issued)
     __syncthreads();
+    W6_STAMP();                                       // 43: everybody done
+    // The stores below sit in per-tile predicated blocks; the compiler's wait-count pass cannot prove across their joins that the two loads
+    // above have landed and would put `s_waitcnt vmcnt(0)` in front of every store — which also waits for the previous STORE to retire
+    // (measured: 340 ns per store, 26 us of a 76 us workgroup).  Wait once here and hand the values over through an asm the pass
+    // cannot see through: from now on they are plain register values.
+    asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(sc), "+v"(sh) : : "memory");
     float* ex = smem;
     const bool do_relu = co < a.relu_upto;
     float gs = 0.f, gss = 0.f;
@@ -311,7 +363,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
                 }
             }
         }
+        W6_STAMP();                                   // 44 / 47: round written
         __syncthreads();
+        W6_STAMP();                                   // 45 / 48: round visible
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             // P[a][j]: rows 0..3 from waves 0..3 (values 0..3), row 4 = halves of waves 0, 1, row 5 = halves of waves 2, 3 (values 4..7)
@@ -337,6 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
             const int oh = oh0 + 4 * mt, ow = ow0 + 4 * mtc;
             const bool tile_ok = cvalid && m < W6_TR * W6_TC;
             float* yp0 = yimg + ((long)oh * W + ow) * a.y_cs;
+            float yv[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float s1 = Pm[1][j] + Pm[2][j], d1 = Pm[1][j] - Pm[2][j], s2 = Pm[3][j] + Pm[4][j], d2 = Pm[3][j] - Pm[4][j];
@@ -345,23 +400,44 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
                 y[1] = d1 + 2.0f * d2;
                 y[2] = s1 + 4.0f * s2;
                 y[3] = d1 + 8.0f * d2 + Pm[5][j];
-                const bool colok = tile_ok && (ow + j < W);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float v = y[i] * sc + sh;
                     if (do_relu) v = fmaxf(v, 0.f);
-                    if (colok && (oh + i < H)) {
-                        yp0[((long)i * W + j) * a.y_cs] = v;
-                        gs += v;
-                        gss = fmaf(v, v, gss);
-                    }
+                    yv[i][j] = v;
+                }
+            }
+            if (tile_ok) {
+                if (oh + 4 <= H && ow + 4 <= W) {           // interior tile: 16 stores, no per-store predicate
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            yp0[((long)i * W + j) * a.y_cs] = yv[i][j];
+                            gs += yv[i][j];
+                            gss = fmaf(yv[i][j], yv[i][j], gss);
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (oh + i < H && ow + j < W) {
+                                yp0[((long)i * W + j) * a.y_cs] = yv[i][j];
+                                gs += yv[i][j];
+                                gss = fmaf(yv[i][j], yv[i][j], gss);
+                            }
                 }
             }
         }
+        W6_STAMP();                                   // 46 / 49: round stored
         if (q == 0) __syncthreads();                        // the exchange buffer is reused by round 1
     }
     // fused GroupNorm statistics of the NEXT layer's normalisation (fcos.py:182-186): one {sum, sumsq} record per
     // (spatial tile, wave, group)
+#ifdef W6_TRACE
+    if (trc) trc[62] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (a.gn_ws) {
         for (int o = 1; o < a.gn_cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
         gs += __shfl_xor(gs, 32);

@@ -114,7 +114,7 @@ def pack_wino6_weight(w: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     cout, cin = w.shape[0], w.shape[1]
     u = torch.einsum("ik,ockl,jl->ocij", _WINO6_G, w.detach().double().cpu(), _WINO6_G)              # (O, C, 6, 6)
-    cin_pad, nt = (cin + 7) // 8 * 8, (cout + 31) // 32
+    cin_pad, nt = (cin + 15) // 16 * 16, (cout + 31) // 32       # the same channel padding as the direct layout (PackedConv.cin_pad)
     up = torch.zeros((nt * 32, cin_pad, 6, 6), dtype=torch.float64)
     up[:cout, :cin] = u
     fa = torch.tensor([[wv if k < 6 else 4 + wv // 2 for k in range(9)] for wv in range(4)])
@@ -122,7 +122,7 @@ def pack_wino6_weight(w: torch.Tensor) -> torch.Tensor:
     sel = up[:, :, fa, fb]                                                                               # (O, C, 4 waves, 9 slots)
     r = sel.reshape(nt, 32, cin_pad // 8, 2, 4, 4, 9)                                                    # [tile][li][chunk][hh][j][wave][slot]
     r = r.permute(2, 0, 5, 6, 3, 1, 4).contiguous().float()                                             # [chunk][tile][wave][slot][hh][li][j]
-    assert r.numel() == lib.cmk_wino6_packed_floats(cout, cin)
+    assert r.numel() == lib.cmk_wino6_packed_floats(cout, cin_pad)
     return r.reshape(cin_pad // 8, nt, 4, 9, 64, 4)
 
 
@@ -377,7 +377,8 @@ def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Te
         e0.record()
         check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi")
         e1.record()
-        PROFILE.append((_kernel_name(taps, 1, _TUNED.get(key), in_affine is not None), flops, nbytes, e0, e1, None))
+        PROFILE.append((_kernel_name(taps, 1, _TUNED.get(key), in_affine is not None), flops, nbytes, e0, e1, None,
+                        executed_flops(taps, 1, _TUNED.get(key), [tuple(y.t.shape[:3]) for y in ys], pc.cin_pad, pc.cout)))
 
     d0 = descs[0]
     cpg = pc.cout // groups if groups > 0 and pc.cout % groups == 0 else 0
@@ -673,7 +674,40 @@ def mask_iou_score(iou: torch.Tensor, scores: torch.Tensor, cls: torch.Tensor) -
 # ---------------------------------------------------------------------------------------------------------------
 # optional per-launch timing (bench.py's roofline leg): events on the launch stream around every conv
 # ---------------------------------------------------------------------------------------------------------------
-PROFILE = None       # when a list, conv2d appends (kernel_key, flops, algorithmic_bytes, start_event, end_event)
+PROFILE = None       # when a list, conv2d appends (kernel_key, flops, algorithmic_bytes, start_event, end_event, shape, executed_flops)
+
+
+def kernel_source_hash() -> str:
+    """Hash of the conv kernel sources the loaded library was built from (the tree travels with the .so): PMC summaries under
+    profiles/ carry it, so a summary of an older kernel is detected instead of quoted."""
+    import hashlib
+    import os
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for f in ("conv_args.hpp", "conv_igemm.hip", "conv_wino6.hip"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) -> float:
+    """FLOPs the matrix pipe EXECUTES for a conv launch, tile padding included (what a roofline fraction must be priced on; the
+    direct-convolution count is the algorithmic figure).  shapes: [(N, Ho, Wo)] per problem of the launch.
+    Winograd forms: 16 (F(2x2)) / 36 (F(4x4)) frequency GEMMs per tile of 2x2 / 4x4 outputs, 32 tiles x 32 couts per MFMA block."""
+    cd = lambda a, b: -(-a // b)
+    wm, sc, wn = (tuple(tv[:3]) if tv else (0, 0, 0))
+    if wm == 5:      # workgroup = 8x16 outputs x 64 couts: 256 MFMAs of 4096 FLOP per 16-channel chunk
+        return float(sum(n * cd(h, 8) * cd(w, 16) for n, h, w in shapes) * cd(cout, 64) * (cin_pad // 16) * 256 * 4096)
+    if wm == 6:      # workgroup = 12x40 outputs x 32 couts: 144 MFMAs per 8-channel chunk
+        return float(sum(n * cd(h, 12) * cd(w, 40) for n, h, w in shapes) * cd(cout, 32) * (cin_pad // 8) * 144 * 4096)
+    cout_pad = _lib.load().cmk_conv_cout_pad(cout)
+    if wm not in (1, 2):                      # cost-model / gather / split-K variants: geometry of the smallest tile
+        wm, sc = 1, (32 if taps == 1 else 16)
+    if taps == 9 and tuple(tv[:1]) != (7,):
+        thh, tww = (32 // sc) * 4 * wm, sc
+        tiles = sum(n * cd(h, thh) * cd(w, tww) for n, h, w in shapes)
+    else:
+        tiles = sum(cd(n * h * w, 128 * wm) for n, h, w in shapes)
+    return float(tiles) * (128 * wm) * cout_pad * taps * cin_pad * 2.0
 
 _conv2d_plain = conv2d
 
@@ -703,12 +737,14 @@ def conv2d(x, pc, y, **kw):  # noqa: F811
     nbytes = 4.0 * (n * h * w * pc.cin + n * ho * wo * pc.cout + pc.cin * pc.cout * taps)
     descs = (ConvDesc * 1)()
     _fill_desc(descs[0], x, pc, y, kw.get("relu", False), kw.get("relu_upto"), kw.get("res"), kw.get("res_upsample", False), kw.get("in_relu", False))
-    key = _kernel_name(taps, pc.stride, _TUNED.get(_problem_key(descs, 1)))
+    tv = _TUNED.get(_problem_key(descs, 1))
+    key = _kernel_name(taps, pc.stride, tv)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _conv2d_plain(x, pc, y, **kw)
     e1.record()
-    PROFILE.append((key, flops, nbytes, e0, e1, (n, h, w, pc.cin, pc.cout, pc.k, pc.stride)))
+    PROFILE.append((key, flops, nbytes, e0, e1, (n, h, w, pc.cin, pc.cout, pc.k, pc.stride),
+                    executed_flops(taps, pc.stride, tv, [(n, ho, wo)], pc.cin_pad, pc.cout)))
 
 
 _conv2d_multi_plain = conv2d_multi
@@ -730,7 +766,9 @@ def conv2d_multi(xs, pcs, ys, **kw):  # noqa: F811
     for i in range(len(xs)):
         _fill_desc(descs[i], xs[i], pcs[i], ys[i], kw.get("relu", False), kw.get("relu_upto"), None, False, False,
                    kw["in_affine"][i] if kw.get("in_affine") is not None else None)
-    PROFILE.append((_kernel_name(taps, 1, _TUNED.get(_problem_key(descs, len(xs))), kw.get("in_affine") is not None), flops, nbytes, e0, e1, None))
+    tv = _TUNED.get(_problem_key(descs, len(xs)))
+    PROFILE.append((_kernel_name(taps, 1, tv, kw.get("in_affine") is not None), flops, nbytes, e0, e1, None,
+                    executed_flops(taps, 1, tv, [tuple(y.t.shape[:3]) for y in ys], pc.cin_pad, pc.cout)))
 
 
 # ---------------------------------------------------------------------------------------------------------------

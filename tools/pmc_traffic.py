@@ -5,7 +5,10 @@ exact for 16 B/lane stores.   usage: pmc_traffic.py <fetch counter_collection.cs
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter):
@@ -24,5 +27,7 @@ for k in fetch:
         out[k] = {"fetch_bytes_per_launch": 2.0 * 1024.0 * fetch[k], "write_bytes_per_launch": 1024.0 * write.get(k, 0.0),
                   "hbm_bytes_per_launch": 2.0 * 1024.0 * fetch[k] + 1024.0 * write.get(k, 0.0), "launches_sampled": nf[k],
                   "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count of wide reads), WRITE_SIZE KiB x1024"}
+from centermask2_amd.ops import kernel_source_hash
+out["_kernel_source_hash"] = kernel_source_hash()          # bench.py quotes a summary only while this matches the built sources
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print("wrote", sys.argv[3], len(out), "kernels")
