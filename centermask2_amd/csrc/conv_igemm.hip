@@ -952,6 +952,26 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     } else {
         // untuned default: the 2-WG/CU Winograd form wins on every 3x3 stride-1 shape measured (tools/bench_wino.py), so take it
         // whenever the caller packed the transformed weights; otherwise the direct-kernel cost model decides
+        // F(4x4,3x3) where its 12x40 tiles are reasonably full and there are enough of them (measured on the model's maps, tools/bench_wino6.py:
+        // 1.1-1.5x the 2x2 form down to 25x40 maps, 0.4x on 14x14 RoI maps whose tiles are 20 % full)
+        if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && d->w_wino6 && d->Cin >= 32 && !(d->Cin & 7) && d->splitk <= 1) {
+            double px = 0.0, covered = 0.0;
+            long wgs = 0;
+            for (int i = 0; i < n; ++i) {
+                const long t = (long)descs[i].N * cdiv(descs[i].H, 12) * cdiv(descs[i].W, 40);
+                px += (double)descs[i].N * descs[i].H * descs[i].W;
+                covered += (double)t * 480.0;
+                wgs += t * cdiv(d->Cout, 32);
+            }
+            if (px >= 0.55 * covered && wgs >= 256) {
+                if (d->gn_ws) {
+                    int rc = setup_gn(a, d);
+                    if (rc) return rc;
+                }
+                a.w = d->w_wino6;
+                return launch_wino6(a, st);
+            }
+        }
         if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && d->w_wino && d->Cin >= 32 && d->splitk <= 1) {
             if (d->gn_ws) {
                 int rc = setup_gn(a, d);

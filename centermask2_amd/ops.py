@@ -297,6 +297,17 @@ def _tune(descs, n, key) -> None:
     _TUNED[key] = best
 
 
+def _default_is_wino6(descs, n, pc) -> bool:
+    """The library's untuned choice between the two Winograd forms (conv_igemm.hip run()): F(4x4,3x3) when its 12x40 tiles are at
+    least 55 % full over the launch and there are at least 256 workgroups."""
+    if getattr(pc, "w_wino6", None) is None or pc.k != 3 or pc.stride != 1 or pc.cin_pad < 32:
+        return False
+    cd = lambda a, b: -(-a // b)
+    px = sum(descs[i].N * descs[i].H * descs[i].W for i in range(n))
+    tiles = sum(descs[i].N * cd(descs[i].H, 12) * cd(descs[i].W, 40) for i in range(n))
+    return px >= 0.55 * tiles * 480 and tiles * cd(pc.cout, 32) >= 256
+
+
 def _default_variant(d):
     """No table entry and no tuner: library defaults, plus split-K for skinny 1x1 GEMMs (maskiou_fc1: 400 x 12544 x 1024)."""
     if d.ksize == 1 and d.res_mode != 2 and _out_pixels(d) <= 1024 and d.Cin >= 4096:
@@ -382,8 +393,9 @@ def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Te
 
     d0 = descs[0]
     cpg = pc.cout // groups if groups > 0 and pc.cout % groups == 0 else 0
-    wino = d0.tune_wm in (5, 6) or ((d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0) and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
-    gn_form = 6 if d0.tune_wm == 6 else 5
+    untuned = (d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0)
+    wino = d0.tune_wm in (5, 6) or (untuned and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
+    gn_form = 6 if (d0.tune_wm == 6 or (untuned and _default_is_wino6(descs, n, pc))) else 5
     fused = wino and 0 < cpg <= 32 and (cpg & (cpg - 1)) == 0 and all(x.t.shape[0] == xs[0].t.shape[0] for x in xs)
     if not fused:
         launch()

@@ -8,8 +8,10 @@ SpatialAttentionMaskHead, MaskIoUHead) to check oracle/centermask_oracle.py and 
 
 What is real and what is not: the reference's own logic runs as written.  The third-party pieces below are
 written from the public behaviour of detectron2 ~0.5 / torchvision 0.9 — FrozenBN, the
-Conv2d wrapper, FPN wiring, ROIAlign, batched_nms — so those stay "parity unpinned"; ROIAlign and nms are served
-by the oracle's C kernels (oracle/oracle_ops.c).
+Conv2d wrapper, FPN wiring, ROIAlign, batched_nms — so those stay "parity unpinned".  ROIAlign and batched_nms are
+restated HERE, independently of the oracle (vectorised torch gather / IoU-row greedy suppression, no code shared with
+oracle/oracle_ops.c), so that a fixture produced through this stub is not the oracle checking itself; hand-derived
+vectors for both live in tests/test_cpu_oracle_golden.py.
 """
 import math
 import os
@@ -27,7 +29,6 @@ if _REPO not in sys.path:
 from centermask2_amd.registry import Registry  # noqa: E402  (fresh instances are created below)
 from centermask2_amd.structures import Boxes, ImageList, Instances, ShapeSpec  # noqa: E402
 from centermask2_amd.config.cfgnode import CfgNode  # noqa: E402
-from oracle import centermask_oracle as O  # noqa: E402
 
 
 class _Placeholder:
@@ -111,6 +112,81 @@ def cat(tensors, dim=0):
     return torch.cat(tensors, dim)
 
 
+def _roi_align_independent(inp, rois, spatial_scale, out_size, sampling_ratio, aligned):
+    """torchvision 0.9 roi_align, restated from its published algorithm with torch tensor ops (one RoI at a time, everything
+    inside vectorised): box * scale (- 0.5 when aligned; unaligned boxes are at least 1x1), bin = size / out,
+    grid = sampling_ratio > 0 ? sampling_ratio : ceil(size / out), samples at start + p*bin + (i + 0.5)*bin/grid, bilinear with
+    the validity rule `y < -1 or y > H -> 0`, `y <= 0 -> 0`, top edge clamped to H-1, mean over grid_h*grid_w (at least 1)."""
+    n_rois, (C, H, W) = rois.shape[0], inp.shape[1:]
+    out = torch.zeros((n_rois, C, out_size, out_size), dtype=torch.float32)
+    f32 = torch.float32
+    for r in range(n_rois):
+        b = int(rois[r, 0])
+        off = 0.5 if aligned else 0.0
+        x1, y1, x2, y2 = [rois[r, k].to(f32) * f32_(spatial_scale) - f32_(off) for k in (1, 2, 3, 4)]
+        rw, rh = x2 - x1, y2 - y1
+        if not aligned:
+            rw, rh = torch.clamp(rw, min=1.0), torch.clamp(rh, min=1.0)
+        bw, bh = rw / f32_(out_size), rh / f32_(out_size)
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(float(rh) / out_size))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(float(rw) / out_size))
+        count = max(gh * gw, 1)
+        if gh <= 0 or gw <= 0:
+            continue
+        p = torch.arange(out_size, dtype=f32)
+        ys = (y1 + p[:, None] * bh + (torch.arange(gh, dtype=f32)[None, :] + 0.5) * bh / f32_(gh)).reshape(-1)     # (out*gh)
+        xs = (x1 + p[:, None] * bw + (torch.arange(gw, dtype=f32)[None, :] + 0.5) * bw / f32_(gw)).reshape(-1)     # (out*gw)
+
+        def axis(c, size):
+            valid = ~((c < -1.0) | (c > size))
+            c = torch.clamp(c, min=0.0)
+            lo = c.to(torch.int64)
+            top = lo >= size - 1
+            lo = torch.where(top, torch.full_like(lo, size - 1), lo)
+            hi = torch.where(top, lo, lo + 1)
+            c = torch.where(top, lo.to(f32), c)
+            frac = c - lo.to(f32)
+            return valid, lo, hi, frac
+        vy, ylo, yhi, ly = axis(ys, H)
+        vx, xlo, xhi, lx = axis(xs, W)
+        hy, hx = 1.0 - ly, 1.0 - lx
+        img = inp[b].to(f32)                                                  # (C, H, W)
+        g = lambda yi, xi: img[:, yi][:, :, xi]                               # (C, len(y), len(x))
+        val = (hy[:, None] * hx[None, :]) * g(ylo, xlo) + (hy[:, None] * lx[None, :]) * g(ylo, xhi) \
+            + (ly[:, None] * hx[None, :]) * g(yhi, xlo) + (ly[:, None] * lx[None, :]) * g(yhi, xhi)
+        val = val * (vy[:, None] & vx[None, :]).to(f32)
+        out[r] = val.reshape(C, out_size, gh, out_size, gw).sum(dim=(2, 4)) / f32_(count)
+    return out
+
+
+def f32_(v):
+    return torch.tensor(float(v), dtype=torch.float32)
+
+
+def _nms_independent(boxes, scores, thr):
+    """torchvision nms: descending score (stable), a box is dropped when its IoU with an already kept box is > thr;
+    areas (x2-x1)*(y2-y1), no +1.  One IoU row per KEPT box against everything after it."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    b = boxes[order].float()
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    dead = torch.zeros(n, dtype=torch.bool)
+    keep = []
+    for i in range(n):
+        if dead[i]:
+            continue
+        keep.append(i)
+        if i + 1 < n:
+            xx1 = torch.maximum(b[i, 0], b[i + 1:, 0]); yy1 = torch.maximum(b[i, 1], b[i + 1:, 1])
+            xx2 = torch.minimum(b[i, 2], b[i + 1:, 2]); yy2 = torch.minimum(b[i, 3], b[i + 1:, 3])
+            inter = torch.clamp(xx2 - xx1, min=0) * torch.clamp(yy2 - yy1, min=0)
+            iou = inter / (area[i] + area[i + 1:] - inter)
+            dead[i + 1:] |= iou > thr
+    return order[torch.tensor(keep, dtype=torch.int64)]
+
+
 class ROIAlign(nn.Module):
     def __init__(self, output_size, spatial_scale, sampling_ratio, aligned=True):
         super().__init__()
@@ -121,11 +197,23 @@ class ROIAlign(nn.Module):
 
     def forward(self, input, rois):
         assert rois.dim() == 2 and rois.size(1) == 5
-        return O.roi_align(input, rois, self.spatial_scale, self.output_size[0], self.sampling_ratio, self.aligned)
+        return _roi_align_independent(input, rois, self.spatial_scale, self.output_size[0], self.sampling_ratio, self.aligned)
 
 
 def batched_nms(boxes, scores, idxs, iou_threshold):
-    return O.batched_nms(boxes, scores, idxs, iou_threshold)
+    """detectron2 batched_nms: < 40000 boxes -> torchvision's coordinate trick (boxes + idxs * (max + 1)), one nms;
+    otherwise nms per class and the kept indices re-sorted by score."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    if boxes.shape[0] < 40000:
+        offsets = idxs.to(boxes) * (boxes.max() + torch.tensor(1).to(boxes))
+        return _nms_independent(boxes + offsets[:, None], scores, iou_threshold)
+    mask = torch.zeros(boxes.shape[0], dtype=torch.bool)
+    for cid in torch.unique(idxs).tolist():
+        sel = (idxs == cid).nonzero().view(-1)
+        mask[sel[_nms_independent(boxes[sel], scores[sel], iou_threshold)]] = True
+    keep = mask.nonzero().view(-1)
+    return keep[torch.sort(scores[keep], descending=True, stable=True)[1]]
 
 
 class Backbone(nn.Module):

@@ -96,3 +96,82 @@ def test_nms_and_level_edge_cases():
     assert O.roi_align(f, torch.zeros((0, 5)), 0.5, 14, 0, True).shape == (0, 4, 14, 14)
     z = O.roi_align(f, torch.tensor([[1., 3., 3., 3., 3.]]), 1.0, 2, 0, True)
     assert float(z.abs().max()) == 0.0      # grid = ceil(0) = 0 samples -> 0 (torchvision behaviour)
+
+
+# ---- hand-derived vectors for the third-party arithmetic (torchvision roi_align / nms, d2 batched_nms) ------------------------------
+# These do not come from any implementation: each expectation follows from the published definition by hand, so they pin the oracle
+# (and through tests/golden/d2_stub.py's independent restatement, the fixtures) without the oracle checking itself.
+def test_roi_align_constant_map_gives_constant_output():
+    f = torch.full((1, 3, 20, 30), 2.5)
+    out = O.roi_align(f, torch.tensor([[0., 16., 24., 200., 130.], [0., 40.25, 17.5, 41.0, 150.]]), 1 / 8, 14, 0, True)
+    assert float((out - 2.5).abs().max()) == 0.0                      # every sample lies inside the map: mean of equal values
+
+
+def test_roi_align_linear_ramp_is_exact_at_bin_centres():
+    """Bilinear interpolation reproduces a linear function, and the mean over a bin's regular sample grid is the value at the bin
+    centre: out[ph, pw] = f(y0 + (ph + .5) bh, x0 + (pw + .5) bw) with y0 = y1*s - .5 (aligned), bh = (y2 - y1) s / P."""
+    H, W, P, s = 24, 40, 14, 1 / 8
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    f = (0.25 * xx - 0.5 * yy + 3.0)[None, None]
+    x1, y1, x2, y2 = 48.0, 40.0, 272.0, 152.0                          # in feature pixels: x 5.5..33.5, y 4.5..18.5 — all samples interior
+    out = O.roi_align(f, torch.tensor([[0., x1, y1, x2, y2]]), s, P, 0, True)[0, 0]
+    bh, bw = (y2 - y1) * s / P, (x2 - x1) * s / P
+    ph = torch.arange(P, dtype=torch.float32)
+    cy, cx = y1 * s - 0.5 + (ph + 0.5) * bh, x1 * s - 0.5 + (ph + 0.5) * bw
+    want = 0.25 * cx[None, :] - 0.5 * cy[:, None] + 3.0
+    assert float((out - want).abs().max()) < 2e-6
+
+
+def test_roi_align_validity_boundary_at_minus_one_and_size():
+    """torchvision: a sample with y < -1 or y > H contributes 0; y == -1 and y == H are still valid (clamped to the edge pixel)."""
+    H, W = 4, 4
+    f = torch.full((1, 1, H, W), 7.0)
+    # P = 1, sampling_ratio 1: the single sample sits at the box centre.  aligned -> centre = (c1 + c2)/2 * s - 0.5 with s = 1.
+    def centre_value(cy, cx):
+        return float(O.roi_align(f, torch.tensor([[0., cx + 0.5 - 1.0, cy + 0.5 - 1.0, cx + 0.5 + 1.0, cy + 0.5 + 1.0]]), 1.0, 1, 1, True)[0, 0, 0, 0])
+    assert centre_value(-1.0, 1.5) == 7.0                               # exactly -1: valid, clamped to row 0
+    assert centre_value(-1.0 - 2 ** -10, 1.5) == 0.0                    # just outside
+    assert centre_value(float(H), 1.5) == 7.0                           # exactly H: valid, clamped to row H-1
+    assert centre_value(H + 2 ** -10, 1.5) == 0.0
+    assert centre_value(1.5, -1.0) == 7.0 and centre_value(1.5, float(W)) == 7.0
+    assert centre_value(1.5, W + 2 ** -10) == 0.0
+    # the top edge: y in (H-1, H] interpolates between row H-1 and itself
+    g = torch.arange(16, dtype=torch.float32).reshape(1, 1, 4, 4)
+    v = float(O.roi_align(g, torch.tensor([[0., 0.5, 3.25 + 0.5 - 1.0, 2.5, 3.25 + 0.5 + 1.0]]), 1.0, 1, 1, True)[0, 0, 0, 0])
+    assert v == 12.0 + 1.0                                              # sample (y 3.25 -> row 3, x 1.0): g[3][1] = 13
+
+
+def test_nms_threshold_is_strict_and_areas_have_no_plus_one():
+    """IoU exactly at, above and below 0.6 against box A = [0,0,10,10] (area 100, no +1): B = [0,0,10,6] has IoU 60/100 = 0.6 ->
+    kept (suppression needs IoU > thr); C = [0,0,10,6.25] has 62.5/100 -> dropped; D = [0,0,10,5.75] -> kept."""
+    A = [0., 0., 10., 10.]
+    for other, kept in (([0., 0., 10., 6.], True), ([0., 0., 10., 6.25], False), ([0., 0., 10., 5.75], True)):
+        boxes = torch.tensor([A, other])
+        keep = O.batched_nms(boxes, torch.tensor([0.9, 0.8]), torch.tensor([3, 3]), 0.6)
+        assert keep.tolist() == ([0, 1] if kept else [0]), (other, keep.tolist())
+    # different labels never suppress each other; output is in descending score order
+    boxes = torch.tensor([A, A, A])
+    assert O.batched_nms(boxes, torch.tensor([0.5, 0.7, 0.6]), torch.tensor([1, 2, 3]), 0.6).tolist() == [1, 2, 0]
+    # the same label: only the best survives
+    assert O.batched_nms(boxes, torch.tensor([0.5, 0.7, 0.6]), torch.tensor([2, 2, 2]), 0.6).tolist() == [1]
+
+
+def test_batched_nms_coordinate_trick_rounds_in_float32_at_label_79():
+    """d2/torchvision shift every box by label * (max coordinate + 1) and run ONE nms in float32.  At label 79 with coordinates up
+    to ~1300 the shift is ~1e5, where float32 has a spacing of 2^-7: the IoU is that of the ROUNDED boxes.  Expectation derived
+    with explicit float32 arithmetic below, not from an implementation."""
+    import numpy as np
+    a = np.array([100.03, 200.02, 130.04, 240.01], dtype=np.float32)
+    b = np.array([100.03, 200.02, 130.04, 224.012], dtype=np.float32)           # IoU with a = 0.6000x before the shift
+    far = np.array([1290.0, 790.0, 1300.0, 800.0], dtype=np.float32)              # sets max coordinate = 1300
+    shift = np.float32(79) * (np.float32(1300.0) + np.float32(1))
+    ra, rb = a + shift, b + shift                                                 # float32 adds: rounded to multiples of 2^-7
+    def iou(p, q):
+        iw = max(np.float32(0), min(p[2], q[2]) - max(p[0], q[0])); ih = max(np.float32(0), min(p[3], q[3]) - max(p[1], q[1]))
+        inter = np.float32(iw * ih)
+        return inter / (np.float32((p[2] - p[0]) * (p[3] - p[1])) + np.float32((q[2] - q[0]) * (q[3] - q[1])) - inter)
+    expect_b_kept = not (iou(ra, rb) > np.float32(0.6))
+    assert (iou(a, b) > np.float32(0.6)) != (iou(ra, rb) > np.float32(0.6)), "the case must sit where the rounding decides"
+    boxes = torch.from_numpy(np.stack([a, b, far]))
+    keep = O.batched_nms(boxes, torch.tensor([0.9, 0.8, 0.1]), torch.tensor([79, 79, 0]), 0.6)
+    assert keep.tolist() == ([0, 1, 2] if expect_b_kept else [0, 2])
