@@ -17,7 +17,8 @@ import make_golden as G  # noqa: E402  (installs the d2 stand-ins and imports th
 
 S, O = G.S, G.O
 BODIES = ("V-19-slim-dw-eSE", "V-19-dw-eSE", "V-19-slim-eSE", "V-19-eSE", "V-57-eSE")
-FORWARD = {"V-19-slim-dw-eSE": (2, 76, 108), "V-19-dw-eSE": (1, 64, 96), "V-19-slim-eSE": (1, 76, 108)}
+FORWARD = {"V-19-slim-dw-eSE": (2, 76, 108), "V-19-dw-eSE": (1, 64, 96), "V-19-slim-eSE": (1, 76, 108), "V-19-eSE": (1, 76, 108),
+           "V-57-eSE": (1, 76, 108)}
 
 
 def main():

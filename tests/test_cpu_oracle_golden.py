@@ -33,9 +33,10 @@ def test_backbone_fpn_small():
 
 
 def test_other_vovnet_bodies_incl_depthwise():
-    """V-19-slim-dw / V-19-dw (dw_conv3x3 + conv_reduction, vovnet.py:110-130,284-288) and V-19-slim."""
+    """V-19-slim-dw / V-19-dw (dw_conv3x3 + conv_reduction, vovnet.py:110-130,284-288), V-19-slim, V-19 and V-57
+    (vovnet.py:50-88)."""
     g = golden("vovnet_bodies")
-    assert set(g.keys()) == {"V-19-slim-dw-eSE", "V-19-dw-eSE", "V-19-slim-eSE"}
+    assert set(g.keys()) == {"V-19-slim-dw-eSE", "V-19-dw-eSE", "V-19-slim-eSE", "V-19-eSE", "V-57-eSE"}
     for body, case in g.items():
         sd = S.make_synthetic_state_dict(body, 0)
         out = O.vovnet_forward(sd, case["x"], conv_body=body)
@@ -44,6 +45,20 @@ def test_other_vovnet_bodies_incl_depthwise():
         out = O.backbone_forward(sd, case["x32"], conv_body=body)
         for k in ("p3", "p4", "p5", "p6", "p7"):
             close(out[k], case[k], 1e-6, body + " " + k)
+
+
+def test_v99_end_to_end_800x1280():
+    """BASELINE config 5's body at its image size: the oracle against what the reference's own modules produced (one image)."""
+    g = golden("e2e_v99_800x1280")
+    sd = S.make_synthetic_state_dict("V-99-eSE", 0)
+    x = S.make_synthetic_images(1, 800, 1280, seed0=int(g["image_seed0"]))
+    res = O.centermask_inference(sd, x, [(800, 1280)], "V-99-eSE")[0]
+    r = g["img0"]
+    assert torch.equal(res["classes"], r["classes"]) and torch.equal(res["locations"], r["locations"])
+    close(res["boxes"], r["boxes"], 1e-6)
+    close(res["scores"], r["scores"], 1e-6)
+    close(res["pred_masks"], r["pred_masks"], 1e-5)
+    close(res["mask_scores"], r["mask_scores"], 1e-5)
 
 
 def test_fcos_head_decode_nms_small():
