@@ -32,6 +32,9 @@
 // sam.py:58-70, maskiou_head.py:81-88).
 #include "conv_args.hpp"
 
+#ifndef W6_ABL
+#define W6_ABL 0     // timing ablations (tools/ab): 1 no pass 1, 2 no halo loads, 4 no weight loads, 8 no barrier — results are wrong with any set
+#endif
 #ifndef W6_NOFENCE
 #define W6_FENCE __builtin_amdgcn_sched_barrier(0)
 #else
@@ -56,7 +59,13 @@ constexpr int W6_QP = W6_TR * W6_TP;                   //   channel quad
 constexpr int W6_WB = 2 * W6_QP;                       // one W buffer = 1788 slots
 constexpr int W6_EX_FLOATS = 4 * 4 * 2 * 8 * 64;       // epilogue exchange: [src wave][dst wave][reg of the round][value][lane] = 64 KiB
 constexpr int W6_LDS_BYTES = (2 * W6_WB * 16 > W6_EX_FLOATS * 4) ? 2 * W6_WB * 16 : W6_EX_FLOATS * 4;   // loop 57,216, exchange 65,536: two workgroups per CU
+#ifdef W6_ONE_WG     // experiment: one workgroup per CU (how fast is a workgroup without a partner?)
+#undef W6_LDS_DECL
+constexpr int W6_LDS_ALLOC = 96 * 1024;
+#else
+constexpr int W6_LDS_ALLOC = W6_LDS_BYTES;
 static_assert(2 * W6_LDS_BYTES <= LDS_CU, "two workgroups per CU");
+#endif
 static_assert(W6_ITEMS <= 256, "one pass-1 item per thread");
 
 // W image, in 16-byte slots: entry (channel quad q, tile row t, grid row a, halo column col) lives at
@@ -187,6 +196,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     const long u_chunk = (long)a.grid_y * (36 * 256);
     f32x4 ub[3][3];
     auto load_U = [&](int step, int buf) {          // step = chunk*3 + s
+#if W6_ABL & 4
+        if (step > 2) return;
+#endif
         const int c = step / 3, s = step - c * 3;
         const float* src = u_lane + c * u_chunk + s * (3 * 256);
 #pragma unroll
@@ -278,7 +290,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
         const int wcur = (c & 1) * W6_WB;
         f32x4* wnext = sW + ((c + 1) & 1) * W6_WB;
         const int step = c * 3;
+#if !(W6_ABL & 8)
         __syncthreads();
+#endif
 #ifdef W6_TRACE
         if (c < 40) W6_STAMP();                       // 2 + c: period c entered
 #endif
@@ -290,8 +304,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
         xa = rd(wA + wcur, true, 0);
         half_step(xb, false, 1, 0, 0);
         W6_FENCE;
+#if !(W6_ABL & 1)
         pass1(wnext);
+#endif
+#if !(W6_ABL & 2)
         load_D(min(c + 2, nchunks - 1));
+#endif
         W6_FENCE;
         load_U(min(step + 3, total_steps - 1), 0);
         xb = rd(wA + wcur, true, 1);
@@ -453,9 +471,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
 int launch_wino6(ConvArgs& a, hipStream_t st) {
     static DeviceOnce once;
     int rc = once.run([]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W6_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W6_LDS_ALLOC);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W6_LDS_BYTES);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W6_LDS_ALLOC);
         return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_wino6: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     });
     if (rc) return rc;
@@ -471,9 +489,9 @@ int launch_wino6(ConvArgs& a, hipStream_t st) {
     a.total_tiles = blocks;
     const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y);
     if (a.p[0].in_scale)
-        hipLaunchKernelGGL(conv_wino6_kernel<true>, grid, dim3(256), W6_LDS_BYTES, st, a);
+        hipLaunchKernelGGL(conv_wino6_kernel<true>, grid, dim3(256), W6_LDS_ALLOC, st, a);
     else
-        hipLaunchKernelGGL(conv_wino6_kernel<false>, grid, dim3(256), W6_LDS_BYTES, st, a);
+        hipLaunchKernelGGL(conv_wino6_kernel<false>, grid, dim3(256), W6_LDS_ALLOC, st, a);
     return check_launch("conv_wino6");
 }
 

@@ -95,11 +95,11 @@ class GeneralizedRCNN(nn.Module):
         else:
             detected_instances = [x.to(self.device) for x in detected_instances]
             results = self.roi_heads.forward_with_given_boxes(features, detected_instances)
-        if do_postprocess:
-            from ..postprocess import detector_postprocess
+        if do_postprocess:      # GeneralizedRCNN._postprocess (tester.py:73): d2's detector_postprocess, scale = output size / network input size
+            from ..postprocess import detector_postprocess_d2
             out = []
             for r, inp, size in zip(results, batched_inputs, images.image_sizes):
-                out.append({"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
+                out.append({"instances": detector_postprocess_d2(r, inp.get("height", size[0]), inp.get("width", size[1]))})
             return out
         return results
 

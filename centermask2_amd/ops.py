@@ -22,6 +22,16 @@ def _need_gpu(t: torch.Tensor, what: str) -> None:
         raise _lib.CmkError("{}: tensor is on {}; the CenterMask2 HIP path needs a GPU (no CPU fallback)".format(what, t.device))
     if t.dtype != torch.float32:
         raise _lib.CmkError("{}: expected float32, got {}".format(what, t.dtype))
+    _need_current_device(t, what)
+
+
+def _need_current_device(t: torch.Tensor, what: str) -> None:
+    """The library launches on the stream it is handed — torch's CURRENT stream, i.e. the current device's.  A tensor of another
+    device would be read through a stream (and split-K / GroupNorm workspaces) of the wrong GPU: refuse instead of faulting."""
+    cur = torch.cuda.current_device()
+    if t.device.index is not None and t.device.index != cur:
+        raise _lib.CmkError("{}: tensor lives on cuda:{} but the current device is cuda:{}; wrap the call in "
+                            "`with torch.cuda.device({})` (one process per GPU is the supported layout)".format(what, t.device.index, cur, t.device.index))
 
 
 class View:
@@ -255,7 +265,8 @@ def _set_variant(descs, n, tv):
     ws = None
     if sk > 1:
         d = descs[0]
-        ws = torch.empty((sk * _out_pixels(d) * _lib.load().cmk_conv_cout_pad(d.Cout),), dtype=torch.float32, device="cuda")
+        ws = torch.empty((sk * _out_pixels(d) * _lib.load().cmk_conv_cout_pad(d.Cout),), dtype=torch.float32,
+                         device=torch.device("cuda", torch.cuda.current_device()))       # == the inputs' device (_need_current_device)
         d.splitk, d.splitk_ws = sk, ws.data_ptr()
     return ws
 
@@ -468,6 +479,7 @@ def pack_dw_weight(weight: torch.Tensor) -> torch.Tensor:
 def dwconv3x3(x: View, w9c: torch.Tensor, y: Optional[View] = None, stride: int = 1) -> View:
     """Depth-wise 3x3, pad 1, no bias / activation (vovnet.py:110-119)."""
     lib = _lib.load()
+    _need_gpu(x.t, "dwconv3x3")
     n, h, w = x.nhw
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     if y is None:
@@ -480,6 +492,7 @@ def dwconv3x3(x: View, w9c: torch.Tensor, y: Optional[View] = None, stride: int 
 
 def maxpool3x3s2_ceil(x: View, y: Optional[View] = None, gate: Optional[torch.Tensor] = None) -> View:
     lib = _lib.load()
+    _need_gpu(x.t, "maxpool3x3s2_ceil")
     n, h, w = x.nhw
     ho = -(-(h - 3) // 2) + 1
     wo = -(-(w - 3) // 2) + 1
@@ -504,6 +517,7 @@ def _ese_chunks(hw: int, c: int) -> int:
 def ese_gate(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.Tensor:
     """gate (N,C) = hsigmoid(fc(mean_HW(x)))   (vovnet.py:255-259)."""
     lib = _lib.load()
+    _need_gpu(x.t, "ese_gate")
     n, h, w = x.nhw
     hw, c = h * w, x.c
     chunks = _ese_chunks(hw, c)
@@ -517,6 +531,7 @@ def ese_gate(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.Tensor:
 def ese(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor, y: View, identity: Optional[View] = None) -> None:
     """y = x * hsigmoid(fc(mean_HW(x))) (+ identity)   (vovnet.py:255-260, :329-330)."""
     lib = _lib.load()
+    _need_gpu(x.t, "ese")
     n, h, w = x.nhw
     hw, c = h * w, x.c
     chunks = _ese_chunks(hw, c)
@@ -610,6 +625,7 @@ def nms_topk(cand: dict, iou_thr: float, topk: int):
     lib = _lib.load()
     n, cap = cand["score"].shape
     dev = cand["score"].device
+    _need_gpu(cand["score"], "nms_topk")
     out = dict(box=torch.empty((n, topk, 4), dtype=torch.float32, device=dev),
                score=torch.empty((n, topk), dtype=torch.float32, device=dev),
                cls=torch.empty((n, topk), dtype=torch.int64, device=dev),
@@ -631,6 +647,7 @@ def roi_align_ratio(feats: Sequence[View], scales: Sequence[float], boxes: torch
                     img_area: torch.Tensor, out_size: int, sampling_ratio: int, y: torch.Tensor, min_level: int):
     """feats: dense NHWC levels; boxes (N,topk,4); y: (N*topk,out,out,y_cs) receives channels [0,C).  Returns levels (N*topk) int32."""
     lib = _lib.load()
+    _need_gpu(feats[0].t, "roi_align")
     nl = len(feats)
     n, topk = boxes.shape[0], boxes.shape[1]
     c = feats[0].c
@@ -651,6 +668,7 @@ def roi_align_ratio(feats: Sequence[View], scales: Sequence[float], boxes: torch
 
 def spatial_attention_(x: torch.Tensor, w: torch.Tensor, counts: torch.Tensor, topk: int) -> None:
     lib = _lib.load()
+    _need_gpu(x, "spatial_attention")
     r, s, _, c = x.shape
     check(lib.cmk_spatial_attention(x.data_ptr(), w.data_ptr(), counts.data_ptr(), topk, r, s, c, _stream()), "cmk_spatial_attention")
 
@@ -659,6 +677,7 @@ def mask_predict(dec: torch.Tensor, pw: torch.Tensor, pb: torch.Tensor, cls: tor
                  want_logits: bool = False):
     """dec: (R,S,S,4*C) relu(deconv); returns masks (R,1,2S,2S) [, selected-class logits (R,2S,2S)]."""
     lib = _lib.load()
+    _need_gpu(dec, "mask_predict")
     r, s = dec.shape[0], dec.shape[1]
     c = dec.shape[3] // 4
     masks = torch.empty((r, 1, 2 * s, 2 * s), dtype=torch.float32, device=dec.device)

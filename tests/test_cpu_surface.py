@@ -245,3 +245,19 @@ def test_wire_formats_bin_and_coco_json(tmp_path):
     seg = wire.segm_results_ranked_by_mask_score(js)
     assert "bbox" not in seg[0] and seg[0]["score"] == pytest.approx(0.5) and "mask_score" not in seg[0] and js[0]["score"] == pytest.approx(0.9)
     assert wire.instances_to_coco_json(inst[torch.zeros(2, dtype=torch.bool)], 1) == []
+
+
+def test_device_mismatch_is_refused(monkeypatch):
+    """The wrappers launch on torch's current stream: a tensor that lives on another GPU than the current one must be refused
+    (it used to launch on GPU 0 with GPU-1 pointers).  No GPU needed: the check reads only attributes."""
+    from centermask2_amd import ops
+    from centermask2_amd._lib import CmkError
+
+    class FakeCuda1:
+        is_cuda, dtype, device = True, torch.float32, torch.device("cuda", 1)
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    with pytest.raises(CmkError, match="current device is cuda:0"):
+        ops._need_gpu(FakeCuda1(), "conv2d")
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    ops._need_gpu(FakeCuda1(), "conv2d")                    # same device: accepted

@@ -206,18 +206,32 @@ def test_config5_v99_batch8_800x1280(dev):
 
 
 def test_inference_with_pre_and_postprocess(dev, model):
-    """GeneralizedRCNN.inference on raw uint8-valued images (tester.py:25-75 with do_preprocess/do_postprocess)."""
+    """GeneralizedRCNN.inference on raw uint8-valued images (tester.py:25-75 with do_preprocess/do_postprocess): the post-processed
+    boxes are EXACTLY the raw boxes times (output size / network input size), clipped — d2's rule, not the 800/1333 rule of the
+    deployment path — and images without height/width keys come back at the network input size, unscaled."""
     g = torch.Generator().manual_seed(77)
     imgs = [{"image": torch.randint(0, 256, (3, 200, 300), generator=g).float().to(dev), "height": 100, "width": 150},
-            {"image": torch.randint(0, 256, (3, 180, 260), generator=g).to(torch.uint8).to(dev), "height": 90, "width": 130}]
+            {"image": torch.randint(0, 256, (3, 180, 260), generator=g).to(torch.uint8).to(dev), "height": 90, "width": 195},
+            {"image": torch.randint(0, 256, (3, 192, 256), generator=g).float().to(dev)}]
     out = model.inference(imgs)
-    assert len(out) == 2
-    for o, im in zip(out, imgs):
+    raw = model.inference(imgs, do_postprocess=False)
+    torch.cuda.synchronize()
+    assert len(out) == 3
+    for o, r, im in zip(out, raw, imgs):
         inst = o["instances"]
-        assert inst.image_size == (im["height"], im["width"])
+        h_in, w_in = im["image"].shape[-2:]
+        h, w = im.get("height", h_in), im.get("width", w_in)
+        assert inst.image_size == (h, w) and r.image_size == (h_in, w_in)
+        want = r.pred_boxes.tensor.clone()
+        want[:, 0::2] = (want[:, 0::2] * (w / w_in)).clamp(0, w)
+        want[:, 1::2] = (want[:, 1::2] * (h / h_in)).clamp(0, h)
+        keep = ((want[:, 2] - want[:, 0]) > 0) & ((want[:, 3] - want[:, 1]) > 0)
+        assert len(inst) == int(keep.sum())
+        assert torch.equal(inst.pred_boxes.tensor, want[keep]), "boxes must be the raw boxes x (output / input size)"
+        assert torch.equal(inst.scores, r.scores[keep]) and torch.equal(inst.pred_classes, r.pred_classes[keep])
         if len(inst):
-            assert inst.pred_masks.dtype == torch.bool and tuple(inst.pred_masks.shape[1:]) == (im["height"], im["width"])
-            assert float(inst.pred_boxes.tensor[:, 2].max()) <= im["width"] and float(inst.pred_boxes.tensor.min()) >= 0
+            assert inst.pred_masks.dtype == torch.bool and tuple(inst.pred_masks.shape[1:]) == (h, w)
+    assert len(raw[0]) > 0
 
 
 def test_zero_detections_and_capacity_overflow(dev):
