@@ -287,8 +287,7 @@ def main():
             elapsed = float(t.item())
 
         cand = out["cand_counts"].cpu().tolist()
-        cap = model.proposal_generator.candidate_capacity
-        assert max(cand) <= cap, "candidate overflow {} > {}".format(max(cand), cap)
+        assert not bool(out["overflow"].any()), "candidate overflow {} > capacity {} inside the timed region".format(max(cand), out["cand_capacity"])
         dets = out["counts"].cpu().tolist()
 
         result = None

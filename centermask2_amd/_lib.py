@@ -59,7 +59,7 @@ SIGNATURES = {
     "cmk_groupnorm_affine_tiles": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                            POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     "cmk_conv_gn_tiles": (c_int, [c_int, c_int]),
-    "cmk_fcos_select": (c_int, [POINTER(FcosLevel), c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+    "cmk_fcos_select": (c_int, [POINTER(FcosLevel), c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "cmk_fcos_select_ws_len": (c_int64, [POINTER(FcosLevel), c_int, c_int, c_int]),
     "cmk_nms_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int,

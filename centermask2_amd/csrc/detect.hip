@@ -33,18 +33,28 @@ __device__ inline int find_level(const SelLevels& L, int b) {
 }
 
 // K1: per-block candidate counts.  grid = (blocks_per_image, N)
-__global__ __launch_bounds__(256) void sel_count_kernel(const SelLevels L, int C, float thr, int32_t* __restrict__ block_counts) {
+// candidate test of fcos_outputs.py:410-414: sigmoid(cls) > thr, or with THRESH_WITH_CTR sigmoid(cls) * sigmoid(ctr) > thr
+__device__ inline bool is_candidate(const float* lg, const float* rc, int e, int ne, int C, float thr, int with_ctr, float& p) {
+    if (e >= ne) { p = 0.f; return false; }
+    p = sigmoidf_(lg[e]);
+    if (!with_ctr) return p > thr;
+    return p * sigmoidf_(rc[(long)(e / C) * 5 + 4]) > thr;
+}
+
+__global__ __launch_bounds__(256) void sel_count_kernel(const SelLevels L, int C, float thr, int with_ctr, int32_t* __restrict__ block_counts) {
     const int b = blockIdx.x, n = blockIdx.y;
     const int l = find_level(L, b);
     const int e0 = (b - L.blk_begin[l]) * SEL_CHUNK;
     const int ne = L.elems[l];
     const float* lg = L.logits[l] + (long)n * ne;
+    const float* rc = L.regctr[l] + (long)n * (ne / C) * 5;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int cnt = 0;
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
         int e = e0 + wave * 1024 + it * 64 + lane;
-        bool c = (e < ne) && (sigmoidf_(lg[e]) > thr);
+        float p;
+        bool c = is_candidate(lg, rc, e, ne, C, thr, with_ctr, p);
         cnt += __popcll(__ballot(c));
     }
     __shared__ int wc[4];
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(256) void sel_scan_kernel(int32_t* __restrict__ blo
 }
 
 // K3: ordered write of the candidates.  Same geometry as K1.
-__global__ __launch_bounds__(256) void sel_write_kernel(const SelLevels L, int C, float thr, const int32_t* __restrict__ block_offsets,
+__global__ __launch_bounds__(256) void sel_write_kernel(const SelLevels L, int C, float thr, int with_ctr, const int32_t* __restrict__ block_offsets,
                                                        float* __restrict__ cand_box, float* __restrict__ cand_score,
                                                        int32_t* __restrict__ cand_cls, float* __restrict__ cand_loc, int cap) {
     const int b = blockIdx.x, n = blockIdx.y;
@@ -94,7 +104,8 @@ __global__ __launch_bounds__(256) void sel_write_kernel(const SelLevels L, int C
     int cnt = 0;
     for (int it = 0; it < 16; ++it) {
         int e = e0 + wave * 1024 + it * 64 + lane;
-        bool c = (e < ne) && (sigmoidf_(lg[e]) > thr);
+        float p;
+        bool c = is_candidate(lg, rc, e, ne, C, thr, with_ctr, p);
         cnt += __popcll(__ballot(c));
     }
     __shared__ int wc[4];
@@ -106,12 +117,8 @@ __global__ __launch_bounds__(256) void sel_write_kernel(const SelLevels L, int C
     // pass 2: decode and write in flat order
     for (int it = 0; it < 16; ++it) {
         int e = e0 + wave * 1024 + it * 64 + lane;
-        float p = 0.f;
-        bool c = false;
-        if (e < ne) {
-            p = sigmoidf_(lg[e]);
-            c = p > thr;
-        }
+        float p;
+        const bool c = is_candidate(lg, rc, e, ne, C, thr, with_ctr, p);
         unsigned long long m = __ballot(c);
         int dst = base + __popcll(m & lt);
         base += __popcll(m);
@@ -141,6 +148,7 @@ __global__ __launch_bounds__(256) void sel_write_kernel(const SelLevels L, int C
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int NT = 1024;
 constexpr int NW = NT / 64;
+constexpr int MAXK = 1024;      // POST_NMS_TOPK_TEST the keep list (LDS) is sized for
 
 __device__ inline float iou_f(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2, float by2,
                               float barea) {
@@ -163,8 +171,8 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float* __restrict__ 
     __shared__ int wcnt[NW][256];
     __shared__ float red[NW];
     __shared__ float s_maxc;
-    __shared__ float kx1[64], ky1[64], kx2[64], ky2[64], karea[64];
-    __shared__ int kcls[64];
+    __shared__ float kx1[MAXK], ky1[MAXK], kx2[MAXK], ky2[MAXK], karea[MAXK];
+    __shared__ int kcls[MAXK];
     __shared__ int s_nkept;
 
     const int n = blockIdx.x;
@@ -347,7 +355,7 @@ extern "C" int64_t cmk_fcos_select_ws_len(const cmk_fcos_level* levels, int num_
     return blk < 0 ? -1 : (int64_t)blk * N;
 }
 
-extern "C" int cmk_fcos_select(const cmk_fcos_level* levels, int num_levels, int N, int C, float pre_nms_thresh, float* cand_box,
+extern "C" int cmk_fcos_select(const cmk_fcos_level* levels, int num_levels, int N, int C, float pre_nms_thresh, int thresh_with_ctr, float* cand_box,
                                float* cand_score, int32_t* cand_cls, float* cand_loc, int32_t* counts, int32_t* block_counts,
                                int64_t block_counts_len, int cap, void* stream) {
     if (!levels || !cand_box || !cand_score || !cand_cls || !cand_loc || !counts || !block_counts)
@@ -360,13 +368,13 @@ extern "C" int cmk_fcos_select(const cmk_fcos_level* levels, int num_levels, int
         if (!levels[l].logits || !levels[l].regctr) return fail(CMK_EINVAL, "fcos_select: null level pointer%s", "");
     if (block_counts_len < (int64_t)blk * N) return fail(CMK_EINVAL, "fcos_select: workspace too small%s", "");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sel_count_kernel, dim3(blk, N), dim3(256), 0, st, L, C, pre_nms_thresh, block_counts);
+    hipLaunchKernelGGL(sel_count_kernel, dim3(blk, N), dim3(256), 0, st, L, C, pre_nms_thresh, thresh_with_ctr, block_counts);
     int rc = check_launch("sel_count");
     if (rc) return rc;
     hipLaunchKernelGGL(sel_scan_kernel, dim3(N), dim3(256), 0, st, block_counts, blk, counts);
     rc = check_launch("sel_scan");
     if (rc) return rc;
-    hipLaunchKernelGGL(sel_write_kernel, dim3(blk, N), dim3(256), 0, st, L, C, pre_nms_thresh, block_counts, cand_box, cand_score,
+    hipLaunchKernelGGL(sel_write_kernel, dim3(blk, N), dim3(256), 0, st, L, C, pre_nms_thresh, thresh_with_ctr, block_counts, cand_box, cand_score,
                        cand_cls, cand_loc, cap);
     return check_launch("sel_write");
 }
@@ -377,7 +385,7 @@ extern "C" int cmk_nms_topk(const float* cand_box, const float* cand_score, cons
     if (!cand_box || !cand_score || !cand_cls || !cand_loc || !counts || !out_box || !out_score || !out_cls || !out_loc || !out_idx ||
         !out_count || !sort_ws)
         return fail(CMK_EINVAL, "nms_topk: null pointer%s", "");
-    if (N < 1 || cap < 1 || topk < 1 || topk > 64) return fail(CMK_EINVAL, "nms_topk: need 1 <= topk <= 64%s", "");
+    if (N < 1 || cap < 1 || topk < 1 || topk > MAXK) return fail(CMK_EINVAL, "nms_topk: need 1 <= topk <= %s%ld", "", (long)MAXK);
     hipLaunchKernelGGL(nms_topk_kernel, dim3(N), dim3(NT), 0, (hipStream_t)stream, cand_box, cand_score, cand_cls, cand_loc, counts, cap,
                        iou_thr, topk, out_box, out_score, out_cls, out_loc, out_idx, out_count, sort_ws);
     return check_launch("nms_topk");

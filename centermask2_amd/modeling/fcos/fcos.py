@@ -145,15 +145,15 @@ class FCOS(HipModule):
         self.pre_nms_topk_test = cfg.MODEL.FCOS.PRE_NMS_TOPK_TEST      # unused by the fork (fcos_outputs.py:444-449)
         self.nms_thresh = cfg.MODEL.FCOS.NMS_TH
         self.post_nms_topk_test = cfg.MODEL.FCOS.POST_NMS_TOPK_TEST
-        self.thresh_with_ctr = cfg.MODEL.FCOS.THRESH_WITH_CTR
-        if self.thresh_with_ctr:
-            raise NotImplementedError("MODEL.FCOS.THRESH_WITH_CTR=True (False in the reference, defaults.py:34)")
-        if not (1 <= self.post_nms_topk_test <= 64):
-            raise NotImplementedError("POST_NMS_TOPK_TEST must be in [1, 64] (the NMS kernel keeps its survivors in one wave)")
+        self.thresh_with_ctr = cfg.MODEL.FCOS.THRESH_WITH_CTR          # fcos_outputs.py:410-420 (False in the reference recipe)
+        if not (1 <= self.post_nms_topk_test <= 1024):
+            raise NotImplementedError("POST_NMS_TOPK_TEST must be in [1, 1024] (the NMS kernel's keep list lives in LDS)")
         self.mask_on = cfg.MODEL.MASK_ON
         self.fcos_head = FCOSHead(cfg, [input_shape[f] for f in self.in_features])
-        # candidates per image the workspaces are sized for; the reference is unbounded (no pre-NMS top-k), so an
-        # overflow is detected from the device-side count and reported, never silently truncated.
+        # candidates per image the workspaces are sized for.  The reference is unbounded (no pre-NMS top-k, fcos_outputs.py:444-449):
+        # the select kernel reports the TRUE count, `overflow` rides along with the padded results, and wherever the counts are read
+        # on the host (forward(), results_from_padded) an overflow re-runs select + NMS with a capacity sized from the true count
+        # and keeps the larger capacity for later calls — never a silent truncation, never an error.
         self.candidate_capacity = 131072
 
     def _build_packed(self, dev):
@@ -171,31 +171,50 @@ class FCOS(HipModule):
             locations.append(torch.stack((shift_x.reshape(-1), shift_y.reshape(-1)), dim=1) + s // 2)
         return locations
 
-    def forward_padded(self, features):
-        """Device-only path: returns (detections dict padded to (N, topk), candidates dict).  No host sync."""
-        feats = [ops.as_view(features[f]) for f in self.in_features]
-        logits, regctr = self.fcos_head.forward_views(feats)
-        cand = ops.fcos_select(logits, regctr, self.fpn_strides, self.pre_nms_thresh_test, self.candidate_capacity)
+    def _select_nms(self, logits, regctr, cap: int):
+        cand = ops.fcos_select(logits, regctr, self.fpn_strides, self.pre_nms_thresh_test, cap, self.thresh_with_ctr)
         det = ops.nms_topk(cand, self.nms_thresh, self.post_nms_topk_test)
         det["cand_counts"] = cand["counts"]
+        det["cand_capacity"] = cap
+        det["overflow"] = cand["counts"] > cap                       # (N,) bool on the device: candidates beyond `cap` were dropped
+        det["_rerun"] = lambda new_cap: self._select_nms(logits, regctr, new_cap)
         return det, cand
+
+    def forward_padded(self, features):
+        """Device-only path: returns (detections dict padded to (N, topk), candidates dict).  No host sync.  det["overflow"] tells
+        (on the device) whether an image had more candidates than the capacity; resolve_overflow() acts on it at the caller's sync."""
+        feats = [ops.as_view(features[f]) for f in self.in_features]
+        logits, regctr = self.fcos_head.forward_views(feats)
+        return self._select_nms(logits, regctr, self.candidate_capacity)
+
+    def resolve_overflow(self, det: dict) -> dict:
+        """One host sync on the candidate counts: if any image overflowed, select + NMS run again with a capacity sized from the
+        true count (the head is not recomputed) and the capacity is kept for later calls."""
+        worst = int(det["cand_counts"].max())
+        if worst <= det["cand_capacity"]:
+            return det
+        new_cap = 1 << (worst - 1).bit_length()
+        self.candidate_capacity = max(self.candidate_capacity, new_cap)
+        det2, _ = det["_rerun"](new_cap)
+        assert int(det2["cand_counts"].max()) <= new_cap
+        return det2
 
     def forward(self, images, features, gt_instances=None):
         """fcos.py:61-118 (inference branch): -> (list[Instances], {}).  `images` needs len() and .image_sizes."""
         if self.training:
             raise NotImplementedError("training is out of scope of the MI355X inference path")
         det, _ = self.forward_padded(features)
-        return instances_from_padded(det, images.image_sizes, self.candidate_capacity), {}
+        det = self.resolve_overflow(det)
+        return instances_from_padded(det, images.image_sizes), {}
 
 
-def instances_from_padded(det: dict, image_sizes, cap=None) -> List[Instances]:
+def instances_from_padded(det: dict, image_sizes) -> List[Instances]:
     """One host sync: read the per-image counts, slice the padded device buffers into Instances
-    (fields of fcos_outputs.py:458-462).  The padded buffers ride along for CenterROIHeads."""
+    (fields of fcos_outputs.py:458-462).  The padded buffers ride along for CenterROIHeads.  Overflow must have been resolved
+    (FCOS.resolve_overflow) — a truncated candidate set is refused here rather than handed on."""
     counts = det["counts"].cpu().tolist()
-    if cap is not None:
-        over = det["cand_counts"].cpu().tolist()
-        if max(over) > cap:
-            raise RuntimeError("FCOS produced {} candidates > capacity {}; raise FCOS.candidate_capacity".format(max(over), cap))
+    if "cand_capacity" in det and int(det["cand_counts"].max()) > det["cand_capacity"]:
+        raise RuntimeError("FCOS candidates overflowed the capacity {}: call FCOS.resolve_overflow(det) first".format(det["cand_capacity"]))
     out = []
     for i, k in enumerate(counts):
         inst = Instances(tuple(image_sizes[i]))

@@ -68,13 +68,19 @@ class GeneralizedRCNN(nn.Module):
     # -- device-only fast path --------------------------------------------------------------------------------------
     def inference_padded(self, images: torch.Tensor, image_sizes: Sequence[Tuple[int, int]], want=()) -> dict:
         """images: preprocessed (N,3,H,W) on the GPU.  Returns padded device buffers (box, score, cls, loc, counts,
-        pred_masks, mask_scores, cand_counts); no host synchronisation happens here."""
+        pred_masks, mask_scores, cand_counts, overflow); no host synchronisation happens here.  `overflow` (N bools on the device)
+        says whether an image had more FCOS candidates than the capacity the buffers were sized for: results_from_padded()
+        — the caller's sync point — then re-runs the detection tail and the ROI heads with a larger capacity."""
         features = self.backbone(images)
         det, _ = self.proposal_generator.forward_padded(features)
-        return self.roi_heads.forward_padded(features, det, image_sizes, want=want)
+        out = self.roi_heads.forward_padded(features, det, image_sizes, want=want)
+        out["_redo"] = lambda det2: self.roi_heads.forward_padded(features, det2, image_sizes, want=want)
+        return out
 
     def results_from_padded(self, out: dict, image_sizes) -> List[Instances]:
-        insts = instances_from_padded(out, image_sizes, getattr(self.proposal_generator, "candidate_capacity", None))
+        if "cand_capacity" in out and int(out["cand_counts"].max()) > out["cand_capacity"]:      # unbounded like the reference
+            out = out["_redo"](self.proposal_generator.resolve_overflow(out))
+        insts = instances_from_padded(out, image_sizes)
         for i, it in enumerate(insts):
             m = len(it)
             if "pred_masks" in out:

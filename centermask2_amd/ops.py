@@ -596,7 +596,8 @@ def groupnorm_relu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gr
 # ---------------------------------------------------------------------------------------------------------------
 # FCOS post-head: candidate selection, sort + NMS + top-k (all counts stay on the device)
 # ---------------------------------------------------------------------------------------------------------------
-def fcos_select(logits: Sequence[torch.Tensor], regctr: Sequence[torch.Tensor], strides: Sequence[int], thresh: float, cap: int):
+def fcos_select(logits: Sequence[torch.Tensor], regctr: Sequence[torch.Tensor], strides: Sequence[int], thresh: float, cap: int,
+                thresh_with_ctr: bool = False):
     """logits[l]: (N,H,W,C) dense NHWC; regctr[l]: (N,H,W,5).  Returns dict of candidate buffers (N,cap,...) + counts (N)."""
     lib = _lib.load()
     n, c = logits[0].shape[0], logits[0].shape[3]
@@ -616,7 +617,7 @@ def fcos_select(logits: Sequence[torch.Tensor], regctr: Sequence[torch.Tensor], 
                cls=torch.empty((n, cap), dtype=torch.int32, device=dev),
                loc=torch.empty((n, cap, 2), dtype=torch.float32, device=dev),
                counts=torch.empty((n,), dtype=torch.int32, device=dev), cap=cap)
-    check(lib.cmk_fcos_select(lv, nl, n, c, float(thresh), out["box"].data_ptr(), out["score"].data_ptr(), out["cls"].data_ptr(),
+    check(lib.cmk_fcos_select(lv, nl, n, c, float(thresh), int(bool(thresh_with_ctr)), out["box"].data_ptr(), out["score"].data_ptr(), out["cls"].data_ptr(),
                               out["loc"].data_ptr(), out["counts"].data_ptr(), ws.data_ptr(), wslen, cap, _stream()), "cmk_fcos_select")
     return out
 

@@ -151,8 +151,10 @@ typedef struct {
 } cmk_fcos_level;
 /* Per image i the candidates of all levels are appended in level order, location-major / class-minor
  * (the order of torch.nonzero, fcos_outputs.py:429 and Instances.cat :391-392).
- * cand_* have capacity `cap` rows per image; counts[i] receives the true number (may exceed cap => overflow). */
-int cmk_fcos_select(const cmk_fcos_level* levels, int num_levels, int N, int C, float pre_nms_thresh,
+ * cand_* have capacity `cap` rows per image; counts[i] receives the TRUE number: counts[i] > cap means rows beyond cap were dropped —
+ * the caller compares (it already reads the counts) and re-runs with a larger capacity; the reference is unbounded (:444-449).
+ * thresh_with_ctr: MODEL.FCOS.THRESH_WITH_CTR (:410-420): the candidate test is sigmoid(cls)*sigmoid(ctr) > thr instead of sigmoid(cls) > thr. */
+int cmk_fcos_select(const cmk_fcos_level* levels, int num_levels, int N, int C, float pre_nms_thresh, int thresh_with_ctr,
                     float* cand_box /* N*cap*4 */, float* cand_score, int32_t* cand_cls, float* cand_loc /* N*cap*2 */,
                     int32_t* counts /* N */, int32_t* block_counts /* workspace */, int64_t block_counts_len,
                     int cap, void* stream);
@@ -161,7 +163,7 @@ int64_t cmk_fcos_select_ws_len(const cmk_fcos_level* levels, int num_levels, int
 /* ---- batched NMS + top-k (layers/ml_nms.py:93 -> d2 batched_nms; fcos_outputs.py:472-482) --------------------
  * Stable descending sort by score (ties by candidate index), torchvision's coordinate trick
  * (boxes + cls * (max_coord + 1)) for < 40000 candidates, per-class suppression otherwise, greedy IoU > thr,
- * the first `topk` survivors are written.  sort_ws: 4 * N * cap uint32.                                       */
+ * the first `topk` (1..1024) survivors are written.  sort_ws: 4 * N * cap uint32.                                       */
 int cmk_nms_topk(const float* cand_box, const float* cand_score, const int32_t* cand_cls, const float* cand_loc,
                  const int32_t* counts, int N, int cap, float iou_thr, int topk,
                  float* out_box /* N*topk*4 */, float* out_score, int64_t* out_cls, float* out_loc, int32_t* out_idx,

@@ -317,14 +317,14 @@ def select_over_all_levels(per_image: dict, nms_thresh=0.6, post_nms_topk=50) ->
 
 
 def fcos_predict_proposals(logits, bbox_reg, ctrness, strides=(8, 16, 32, 64, 128), pre_nms_thresh=0.05,
-                           nms_thresh=0.6, post_nms_topk=50, return_candidates=False):
+                           nms_thresh=0.6, post_nms_topk=50, return_candidates=False, thresh_with_ctr=False):
     """predict_proposals fcos_outputs.py:372-394: per level r*stride (:384), per-level selection,
     Instances.cat per image in level order p3..p7 (:391-392), select_over_all_levels."""
     N = logits[0].shape[0]
     per_level = []
     for l, (o, r, c, s) in enumerate(zip(logits, bbox_reg, ctrness, strides)):
         loc = compute_locations_per_level(o.shape[2], o.shape[3], s)
-        per_level.append(fcos_single_level(loc, o, r * s, c, pre_nms_thresh))
+        per_level.append(fcos_single_level(loc, o, r * s, c, pre_nms_thresh, thresh_with_ctr))
     out, cands = [], []
     for i in range(N):
         cat = {k: torch.cat([lvl[i][k] for lvl in per_level], dim=0) for k in per_level[0][i].keys()}

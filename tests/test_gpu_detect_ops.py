@@ -20,9 +20,9 @@ def _to_dev_levels(logits, reg, ctr, dev):
     return lg, rc
 
 
-def _run_detect(logits, reg, ctr, dev, cap=65536, topk=50, thr=0.05, nms=0.6):
+def _run_detect(logits, reg, ctr, dev, cap=65536, topk=50, thr=0.05, nms=0.6, with_ctr=False):
     lg, rc = _to_dev_levels(logits, reg, ctr, dev)
-    cand = ops.fcos_select(lg, rc, STRIDES[:len(lg)], thr, cap)
+    cand = ops.fcos_select(lg, rc, STRIDES[:len(lg)], thr, cap, with_ctr)
     det = ops.nms_topk(cand, nms, topk)
     torch.cuda.synchronize()
     return cand, det
@@ -78,6 +78,28 @@ def test_detect_random_levels_vs_oracle(dev, seed, bias):
         assert torch.equal(det["loc"][i, :k].cpu(), oprops[i]["locations"])
         close(det["box"][i, :k], oprops[i]["boxes"], 1e-6)
         close(det["score"][i, :k], oprops[i]["scores"], 1e-6)
+
+
+@pytest.mark.parametrize("topk", [50, 100, 300])
+def test_thresh_with_ctr_and_large_topk_vs_oracle(dev, topk):
+    """MODEL.FCOS.THRESH_WITH_CTR = True (fcos_outputs.py:410-420: the threshold applies to cls*ctr) and POST_NMS_TOPK_TEST beyond
+    one wave (the fork's top-k is whatever the config says, :477-482)."""
+    shapes = [(25, 40), (13, 20), (7, 10), (4, 5), (2, 3)]
+    logits, reg, ctr = _crafted_levels(2, shapes, 11, -2.5)
+    for with_ctr in (False, True):
+        cand, det = _run_detect(logits, reg, ctr, dev, topk=topk, with_ctr=with_ctr)
+        oprops, ocands = O.fcos_predict_proposals(logits, reg, ctr, post_nms_topk=topk, return_candidates=True, thresh_with_ctr=with_ctr)
+        for i in range(2):
+            assert int(cand["counts"][i]) == ocands[i]["scores"].shape[0]
+            k = int(det["counts"][i])
+            assert k == oprops[i]["scores"].shape[0] and (topk == 50 or k > 64)
+            assert torch.equal(det["cls"][i, :k].cpu(), oprops[i]["classes"])
+            assert torch.equal(det["loc"][i, :k].cpu(), oprops[i]["locations"])
+            close(det["box"][i, :k], oprops[i]["boxes"], 1e-6)
+            close(det["score"][i, :k], oprops[i]["scores"], 1e-6)
+    n_plain = O.fcos_predict_proposals(logits, reg, ctr, return_candidates=True)[1][0]["scores"].shape[0]
+    n_ctr = O.fcos_predict_proposals(logits, reg, ctr, return_candidates=True, thresh_with_ctr=True)[1][0]["scores"].shape[0]
+    assert n_ctr < n_plain            # the two rules really select different sets here
 
 
 def test_nms_heavy_overlap_ties_and_threshold_edges(dev):

@@ -236,7 +236,7 @@ def test_inference_with_pre_and_postprocess(dev, model):
 
 def test_zero_detections_and_capacity_overflow(dev):
     """Edge cases of the detection tail: no score above 0.05 anywhere (empty Instances with the right field shapes, the ROI
-    heads run on zero valid slots), and more candidates than the workspace capacity (reported, never silently truncated)."""
+    heads run on zero valid slots), and more candidates than the workspace capacity (re-run with a larger one, never truncated)."""
     from centermask2_amd import synthetic as S
     from centermask2_amd.structures import FakeImageList
     model, _ = build_gpu_model()
@@ -255,13 +255,55 @@ def test_zero_detections_and_capacity_overflow(dev):
     finally:
         head.cls_logits.bias.data += 30.0
         head.invalidate_packed()
-    head.cls_logits.bias.data += 8.0                      # nearly every (location, class) passes the threshold
+    # more candidates than the capacity: the reference is unbounded (fcos_outputs.py:444-449), so the tail is re-run with a
+    # capacity sized from the true count and the results equal those of a run whose capacity was large from the start
+    head.cls_logits.bias.data += 4.0
     head.invalidate_packed()
-    model.proposal_generator.candidate_capacity = 1024
+    fcos = model.proposal_generator
     try:
-        with pytest.raises(RuntimeError, match="capacity"):
-            model.inference(images, do_preprocess=False, do_postprocess=False)
+        want = model.inference(images, do_preprocess=False, do_postprocess=False)
+        torch.cuda.synchronize()
+        assert fcos.candidate_capacity == 131072
+        fcos.candidate_capacity = 1024
+        out = model.inference_padded(x, images.image_sizes)
+        assert bool(out["overflow"].any()) and int(out["cand_counts"].max()) > 1024          # visible on the padded path
+        got = model.results_from_padded(out, images.image_sizes)                               # ... and resolved at the sync point
+        assert fcos.candidate_capacity >= int(out["cand_counts"].max())
+        fcos.candidate_capacity = 1024
+        got2 = model.inference(images, do_preprocess=False, do_postprocess=False)
+        torch.cuda.synchronize()
+        for a, b, c in zip(want, got, got2):
+            assert len(a) == len(b) == len(c) > 0
+            for other in (b, c):
+                assert torch.equal(a.pred_classes, other.pred_classes) and torch.equal(a.pred_boxes.tensor, other.pred_boxes.tensor)
+                assert torch.equal(a.scores, other.scores) and torch.equal(a.pred_masks, other.pred_masks)
     finally:
-        head.cls_logits.bias.data -= 8.0
+        head.cls_logits.bias.data -= 4.0
         head.invalidate_packed()
-        model.proposal_generator.candidate_capacity = 131072
+        fcos.candidate_capacity = 131072
+
+
+def test_thresh_with_ctr_model_matches_oracle(dev):
+    """cfg MODEL.FCOS.THRESH_WITH_CTR True and POST_NMS_TOPK_TEST 100 through build_model (both used to be refused)."""
+    from centermask2_amd import synthetic as S
+    from centermask2_amd.config import get_cfg, config_path
+    from centermask2_amd.modeling import build_model
+    from oracle import centermask_oracle as O
+    cfg = get_cfg()
+    cfg.merge_from_file(config_path("centermask_V_39_eSE_FPN_ms_3x.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.FCOS.THRESH_WITH_CTR", True, "MODEL.FCOS.POST_NMS_TOPK_TEST", 100])
+    cfg.freeze()
+    sd = S.make_synthetic_state_dict("V-39-eSE", 0)
+    m = build_model(cfg).eval()
+    m.load_state_dict(sd)
+    x = S.make_synthetic_images(1, 256, 320, seed0=4321)
+    feats = m.backbone(x.to(dev))
+    det, _ = m.proposal_generator.forward_padded(feats)
+    torch.cuda.synchronize()
+    of = O.backbone_forward(sd, x)
+    lg, reg, ctr = O.fcos_head_forward(sd, [of[k] for k in ("p3", "p4", "p5", "p6", "p7")])
+    want = O.fcos_predict_proposals(lg, reg, ctr, post_nms_topk=100, thresh_with_ctr=True)[0]
+    k = int(det["counts"][0])
+    assert k == want["scores"].shape[0] and k > 64
+    assert torch.equal(det["cls"][0, :k].cpu(), want["classes"]) and torch.equal(det["loc"][0, :k].cpu(), want["locations"])
+    close(det["score"][0, :k], want["scores"], 1e-4, "scores")
