@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--body", default="V-39-eSE")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sustained (>= 5 s) and host-fed runs that follow the timed region")
     ap.add_argument("--no-autotune", action="store_true", help="use the library's cost model instead of the measured conv tile-variant table")
     ap.add_argument("--tune-file", default=None, help="conv variant table (default: centermask2_amd/tuned/mi355x_<body>_b<B>_800x1280.json)")
     ap.add_argument("--save-tuned", action="store_true", help="write the variant table after start-up tuning")
@@ -286,6 +287,53 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
+        # ---- beyond the contract's K steps (extra keys, never `value`): a sustained run and a run fed from the host -------------
+        sustained = fed = None
+        if rank == 0 and world == 1 and not args.no_extras:
+            # (1) >= 5 s of back-to-back steps: the K-step window above is well under a second, too short for the chip to settle
+            # into the clock it holds under this load
+            n_s, t0s = 0, time.perf_counter()
+            while True:
+                for _ in range(10):
+                    step()
+                n_s += 10
+                torch.cuda.synchronize()
+                if time.perf_counter() - t0s >= 5.0:
+                    break
+            t_s = time.perf_counter() - t0s
+            sustained = {"images_per_sec": round(n_s * B / t_s, 2), "seconds": round(t_s, 2), "steps": n_s}
+            # (2) fresh host batches: pinned host memory -> a staging buffer on a copy stream while the previous batch computes,
+            # then one device-to-device copy into the buffer the (captured) step reads.  98 MB per batch over PCIe.
+            host = [S.make_synthetic_images(B, 800, 1280, seed0=1234, first=0).pin_memory() for _ in range(2)]
+            stage = [torch.empty_like(x) for _ in range(2)]
+            copy_stream = torch.cuda.Stream()
+            ready = [torch.cuda.Event() for _ in range(2)]
+            consumed = [torch.cuda.Event() for _ in range(2)]
+            main = torch.cuda.current_stream()
+
+            def upload(i):
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(consumed[i & 1])
+                    stage[i & 1].copy_(host[i & 1], non_blocking=True)
+                    ready[i & 1].record(copy_stream)
+            for ev in consumed:
+                ev.record(main)
+            n_f = 40
+            upload(0)
+            torch.cuda.synchronize()
+            t0f = time.perf_counter()
+            for i in range(n_f):
+                if i + 1 < n_f:
+                    upload(i + 1)
+                main.wait_event(ready[i & 1])
+                x.copy_(stage[i & 1], non_blocking=True)
+                consumed[i & 1].record(main)
+                step()
+            torch.cuda.synchronize()
+            t_f = time.perf_counter() - t0f
+            fed = {"images_per_sec": round(n_f * B / t_f, 2), "steps": n_f, "h2d_bytes_per_step": int(x.numel() * 4),
+                   "how": "pinned host batch -> staging buffer on a copy stream (overlaps the previous step) -> D2D into the step's input"}
+
         cand = out["cand_counts"].cpu().tolist()
         assert not bool(out["overflow"].any()), "candidate overflow {} > capacity {} inside the timed region".format(max(cand), out["cand_capacity"])
         dets = out["counts"].cpu().tolist()
@@ -314,6 +362,9 @@ def main():
                            "weights": "seeded random-init, reference state-dict keys"},
                 "roofline": roof,
             }
+            if sustained is not None:
+                result["sustained"] = sustained
+                result["fed"] = fed
             if cpu is not None:
                 result["cpu_baseline"] = cpu
                 result["ap_delta"] = ap

@@ -41,3 +41,27 @@ def load_shipped_variant_table():
     from centermask2_amd import ops
     path = os.path.join(os.path.dirname(GOLDEN_ROOT), "centermask2_amd", "tuned", "mi355x_V-39-eSE_b8_800x1280.json")
     return ops.load_tuned(path) if os.path.exists(path) else 0
+
+
+def match_detections(a_scores, a_classes, a_locations, b_scores, b_classes, b_locations, tol=1e-4):
+    """perm with b[perm[i]] == a[i] as detections — identified by (class, location), which is unique after per-class NMS — or an
+    AssertionError.  The two lists must hold the SAME detections; their descending-score ORDER may differ only where the scores
+    are within `tol`: descending-score order is defined up to the numeric noise of the scores, and on the deep V-99 body the CPU
+    oracle itself orders two detections 9e-6 apart differently on different hosts (conv reduction order depends on the CPU's
+    vector width and thread count).  Everything else — which detections, their labels, their locations — is exact."""
+    a_scores, b_scores = a_scores.detach().float().cpu(), b_scores.detach().float().cpu()
+    a_classes, b_classes = a_classes.detach().cpu(), b_classes.detach().cpu()
+    a_locations, b_locations = a_locations.detach().float().cpu(), b_locations.detach().float().cpu()
+    assert a_scores.shape == b_scores.shape, (a_scores.shape, b_scores.shape)
+    key = lambda c, l, k: (int(c[k]), float(l[k, 0]), float(l[k, 1]))
+    where = {key(b_classes, b_locations, k): k for k in range(b_scores.shape[0])}
+    assert len(where) == b_scores.shape[0], "(class, location) must identify a detection"
+    perm = []
+    for i in range(a_scores.shape[0]):
+        k = where.get(key(a_classes, a_locations, i))
+        assert k is not None, "detection {} (class {}, location {}) has no counterpart".format(i, int(a_classes[i]), a_locations[i].tolist())
+        assert abs(float(b_scores[k]) - float(b_scores[i])) <= tol, \
+            "detection {} sits at rank {} in the other list and the scores there differ by more than {}: a real order change".format(i, k, tol)
+        perm.append(k)
+    assert sorted(perm) == list(range(len(perm)))
+    return torch.tensor(perm, dtype=torch.int64)

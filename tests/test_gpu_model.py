@@ -3,7 +3,7 @@ Tolerances: features/logits 1e-3 abs-or-rel (north_star "within 1e-3 fp32"), lab
 import pytest
 import torch
 
-from .helpers import build_gpu_model, close, golden
+from .helpers import build_gpu_model, close, golden, match_detections
 
 pytestmark = pytest.mark.gpu
 
@@ -178,16 +178,17 @@ def test_config5_v99_batch8_800x1280(dev):
         torch.set_num_threads(min(16, os.cpu_count() or 1))
         for i in (0, 5):
             want = O.centermask_inference(sd, x[i:i + 1], [(800, 1280)], "V-99-eSE")[0]
-            if i == 0:                                        # oracle == reference fixture on this image (also a not-gpu test)
-                assert torch.equal(want["classes"], refs[0]["classes"])
-                close(want["boxes"], refs[0]["boxes"], 1e-6, "oracle vs reference boxes")
+            if i == 0:      # the oracle on THIS host against the fixture made in the build container (order: see match_detections)
+                r = refs[0]
+                pr = match_detections(want["scores"], want["classes"], want["locations"], r["scores"], r["classes"], r["locations"])
+                close(want["boxes"], r["boxes"][pr], 2e-5, "oracle vs reference boxes")
             inst = res[i]
             assert len(inst) == want["scores"].shape[0] == 50
-            assert torch.equal(inst.pred_classes.cpu(), want["classes"]), "labels differ (image {})".format(i)
-            assert torch.equal(inst.locations.cpu(), want["locations"]), "ROI locations differ (image {})".format(i)
-            close(inst.pred_boxes.tensor, want["boxes"], 2e-5, "boxes")
-            close(inst.scores, want["scores"], 1e-4, "scores")
-            # mask branch on the oracle's boxes (reference API: center_heads.py:413-444)
+            pg = match_detections(want["scores"], want["classes"], want["locations"], inst.scores, inst.pred_classes, inst.locations).to(dev)
+            assert torch.equal(inst.pred_classes[pg].cpu(), want["classes"]) and torch.equal(inst.locations[pg].cpu(), want["locations"])
+            close(inst.pred_boxes.tensor[pg], want["boxes"], 2e-5, "boxes")
+            close(inst.scores[pg], want["scores"], 1e-4, "scores")
+            # mask branch on the oracle's boxes (reference API: center_heads.py:413-444): every ROI compared, none excluded
             given = Instances((800, 1280))
             given.pred_boxes = Boxes(want["boxes"].to(dev))
             given.pred_classes = want["classes"].to(dev)
@@ -198,8 +199,8 @@ def test_config5_v99_batch8_800x1280(dev):
             close(got.pred_masks, want["pred_masks"], 1e-3, "pred_masks on the oracle's boxes")
             close(got.mask_scores, want["mask_scores"], 1e-3, "mask_scores on the oracle's boxes")
             if i == 0:
-                close(got.pred_masks, refs[0]["pred_masks"], 1e-3, "pred_masks vs the reference fixture")
-                close(got.mask_scores, refs[0]["mask_scores"], 1e-3, "mask_scores vs the reference fixture")
+                close(got.pred_masks, refs[0]["pred_masks"][pr], 1e-3, "pred_masks vs the reference fixture")
+                close(got.mask_scores, refs[0]["mask_scores"][pr], 1e-3, "mask_scores vs the reference fixture")
     finally:
         ops._TUNED.clear()
         ops._TUNED.update(saved)
