@@ -66,6 +66,9 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cmk_roi_align_ratio": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_float), c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "cmk_roi_align_pool": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_float), c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                   c_void_p, c_int, c_void_p, c_void_p]),
     "cmk_spatial_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_mask_predict": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p]),

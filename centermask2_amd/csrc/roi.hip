@@ -18,6 +18,10 @@ struct RoiLevels {
     int H[MAXL], W[MAXL];
     float scale[MAXL];
     int num_levels, min_level;
+    int assign_area;          // 0: CenterMask "ratio" rule (pooler.py:80-118); 1: FPN Eqn.(1) by box area (pooler.py:121-152)
+    float canonical_size;     //    canonical_box_size, canonical_level of the area rule
+    int canonical_level;
+    int aligned;              // 1: ROIAlignV2 (pixel-centre shift of 0.5); 0: ROIAlign v1 (no shift, RoI at least 1x1), pooler.py:243-255
 };
 
 // grid = (ceil(out*out / 4), R); block = 4 waves, one output bin each; lanes = channel quads (C == 256 -> 64 lanes).
@@ -49,7 +53,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels L, int C
     // pooler.py:80-118: ceil(max_level - log2(img_area / box_area + eps)), clamped; eps (2.2e-16) is added in fp32
     const float box_area = (bx1 - bx0) * (by1 - by0);
     const int max_level = L.min_level + L.num_levels - 1;
-    float lvf = ceilf((float)max_level - log2f(img_area[n] / box_area + 2.220446049250313e-16f));
+    float lvf = L.assign_area ? floorf((float)L.canonical_level + log2f(sqrtf(box_area) / L.canonical_size + 2.220446049250313e-16f))
+                              : ceilf((float)max_level - log2f(img_area[n] / box_area + 2.220446049250313e-16f));
     lvf = fminf(fmaxf(lvf, (float)L.min_level), (float)max_level);   // NaN (0/0 areas) propagates like torch.clamp; see host note
     int lv = (int)lvf - L.min_level;
     if (!(lv >= 0 && lv < L.num_levels)) lv = 0;
@@ -58,10 +63,12 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiLevels L, int C
     const float* feat = L.feat[lv] + (long)n * L.H[lv] * L.W[lv] * C;
     const int height = L.H[lv], width = L.W[lv];
     const float sc = L.scale[lv];
-    // torchvision roi_align, aligned=True
-    const float roi_start_w = bx0 * sc - 0.5f, roi_start_h = by0 * sc - 0.5f;
-    const float roi_end_w = bx1 * sc - 0.5f, roi_end_h = by1 * sc - 0.5f;
-    const float roi_width = roi_end_w - roi_start_w, roi_height = roi_end_h - roi_start_h;
+    // torchvision roi_align: aligned shifts by half a pixel; the unaligned (v1) form forces the RoI to be at least 1x1
+    const float off = L.aligned ? 0.5f : 0.0f;
+    const float roi_start_w = bx0 * sc - off, roi_start_h = by0 * sc - off;
+    const float roi_end_w = bx1 * sc - off, roi_end_h = by1 * sc - off;
+    float roi_width = roi_end_w - roi_start_w, roi_height = roi_end_h - roi_start_h;
+    if (!L.aligned) { roi_width = fmaxf(roi_width, 1.0f); roi_height = fmaxf(roi_height, 1.0f); }
     const float bin_size_h = roi_height / (float)out_size, bin_size_w = roi_width / (float)out_size;
     const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)out_size);
     const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)out_size);
@@ -209,16 +216,22 @@ __global__ void mask_iou_score_kernel(const float* __restrict__ iou, int iou_cs,
 
 using namespace cmk;
 
-extern "C" int cmk_roi_align_ratio(const float* const* feats, const int* feat_h, const int* feat_w, const float* scales, int num_levels,
-                                   int min_level, int C, const float* boxes, const int32_t* counts, const float* img_area, int N,
-                                   int topk, int out_size, int sampling_ratio, float* y, int y_cs, int32_t* out_level, void* stream) {
-    if (!feats || !feat_h || !feat_w || !scales || !boxes || !counts || !img_area || !y || !out_level)
+extern "C" int cmk_roi_align_pool(const float* const* feats, const int* feat_h, const int* feat_w, const float* scales, int num_levels,
+                                  int min_level, int C, const float* boxes, const int32_t* counts, const float* img_area, int N,
+                                  int topk, int out_size, int sampling_ratio, int aligned, int assign_by_area, float canonical_box_size,
+                                  int canonical_level, float* y, int y_cs, int32_t* out_level, void* stream) {
+    if (!feats || !feat_h || !feat_w || !scales || !boxes || !counts || (!img_area && !assign_by_area) || !y || !out_level)
         return fail(CMK_EINVAL, "roi_align: null pointer%s", "");
+    if (assign_by_area && !(canonical_box_size > 0.f)) return fail(CMK_EINVAL, "roi_align: canonical_box_size must be positive%s", "");
     if (num_levels < 1 || num_levels > MAXL || (C & 3) || y_cs < C || (y_cs & 3) || N < 1 || topk < 1 || out_size < 1)
         return fail(CMK_EINVAL, "roi_align: bad shape%s", "");
     RoiLevels L;
     L.num_levels = num_levels;
     L.min_level = min_level;
+    L.assign_area = assign_by_area ? 1 : 0;
+    L.canonical_size = canonical_box_size;
+    L.canonical_level = canonical_level;
+    L.aligned = aligned ? 1 : 0;
     for (int l = 0; l < MAXL; ++l) {
         bool ok = l < num_levels;
         if (ok && !feats[l]) return fail(CMK_EINVAL, "roi_align: null level%s", "");
@@ -231,6 +244,13 @@ extern "C" int cmk_roi_align_ratio(const float* const* feats, const int* feat_h,
     hipLaunchKernelGGL(roi_align_kernel, dim3(cdiv(out_size * out_size, 4) * (((R + 7) / 8) * 8)), dim3(256), 0, (hipStream_t)stream, L, C, boxes,
                        counts, img_area, topk, out_size, sampling_ratio, y, y_cs, out_level, R);
     return check_launch("roi_align");
+}
+
+extern "C" int cmk_roi_align_ratio(const float* const* feats, const int* feat_h, const int* feat_w, const float* scales, int num_levels,
+                                   int min_level, int C, const float* boxes, const int32_t* counts, const float* img_area, int N,
+                                   int topk, int out_size, int sampling_ratio, float* y, int y_cs, int32_t* out_level, void* stream) {
+    return cmk_roi_align_pool(feats, feat_h, feat_w, scales, num_levels, min_level, C, boxes, counts, img_area, N, topk, out_size,
+                              sampling_ratio, 1, 0, 224.f, 4, y, y_cs, out_level, stream);
 }
 
 extern "C" int cmk_spatial_attention(float* x, const float* w, const int32_t* counts, int topk, int R, int S, int C, void* stream) {

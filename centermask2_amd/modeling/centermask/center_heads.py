@@ -27,17 +27,22 @@ __all__ = ["CenterROIHeads", "ROIPooler", "SpatialAttentionMaskHead", "MaskIoUHe
 
 
 class ROIPooler(nn.Module):
-    """pooler.py:192-288 constructor surface; only ROIAlignV2 is built (the reference config's type)."""
+    """pooler.py:192-288 constructor surface.  ROIAlignV2 (the reference config's type) and ROIAlign v1, level assignment by
+    "ratio" (the reference recipe) or by "area" (FPN Eqn.(1), pooler.py:121-152); ROIPool / ROIAlignRotated are out of scope."""
 
     def __init__(self, output_size, scales, sampling_ratio, pooler_type, canonical_box_size=224, canonical_level=4, assign_crit="area"):
         super().__init__()
         if isinstance(output_size, (tuple, list)):
             assert output_size[0] == output_size[1]
             output_size = output_size[0]
-        if pooler_type != "ROIAlignV2":
-            raise NotImplementedError("pooler_type {} (reference default is ROIAlignV2)".format(pooler_type))
-        if assign_crit != "ratio":
-            raise NotImplementedError("ASSIGN_CRITERION {} (the reference recipe sets 'ratio', Base yaml :22)".format(assign_crit))
+        if pooler_type not in ("ROIAlignV2", "ROIAlign"):
+            raise NotImplementedError("pooler_type {} (ROIAlignV2 / ROIAlign are built; ROIPool and ROIAlignRotated are out of scope)".format(pooler_type))
+        if assign_crit not in ("ratio", "area"):
+            raise ValueError("unknown ASSIGN_CRITERION {}".format(assign_crit))
+        self.aligned = pooler_type == "ROIAlignV2"
+        self.assign_crit = assign_crit
+        assert canonical_box_size > 0
+        self.canonical_box_size, self.canonical_level = canonical_box_size, canonical_level
         self.output_size = output_size
         self.scales = tuple(scales)
         self.sampling_ratio = sampling_ratio
@@ -270,7 +275,9 @@ class CenterROIHeads(HipModule):
         s = pool.output_size
         roi = torch.empty((r, s, s, cpad), dtype=torch.float32, device=dev)
         img_area = self._img_area(image_sizes, dev)                                                               # pooler.py:70-77
-        levels = ops.roi_align_ratio(feats, pool.scales, det["box"], det["counts"], img_area, s, pool.sampling_ratio, roi, pool.min_level)
+        levels = ops.roi_align_ratio(feats, pool.scales, det["box"], det["counts"], img_area, s, pool.sampling_ratio, roi, pool.min_level,
+                                     aligned=pool.aligned, assign_by_area=pool.assign_crit == "area",
+                                     canonical_box_size=pool.canonical_box_size, canonical_level=pool.canonical_level)
         dec = self.mask_head.features(View(roi, 0, c), det["counts"], k)
         P = self.mask_head.packed()
         cls_flat = det["cls"].reshape(-1)

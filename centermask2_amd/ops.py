@@ -645,8 +645,10 @@ def nms_topk(cand: dict, iou_thr: float, topk: int):
 # ROI heads
 # ---------------------------------------------------------------------------------------------------------------
 def roi_align_ratio(feats: Sequence[View], scales: Sequence[float], boxes: torch.Tensor, counts: torch.Tensor,
-                    img_area: torch.Tensor, out_size: int, sampling_ratio: int, y: torch.Tensor, min_level: int):
-    """feats: dense NHWC levels; boxes (N,topk,4); y: (N*topk,out,out,y_cs) receives channels [0,C).  Returns levels (N*topk) int32."""
+                    img_area: torch.Tensor, out_size: int, sampling_ratio: int, y: torch.Tensor, min_level: int,
+                    aligned: bool = True, assign_by_area: bool = False, canonical_box_size: float = 224.0, canonical_level: int = 4):
+    """feats: dense NHWC levels; boxes (N,topk,4); y: (N*topk,out,out,y_cs) receives channels [0,C).  Returns levels (N*topk) int32.
+    aligned False = ROIAlign v1; assign_by_area = FPN Eqn.(1) instead of CenterMask's ratio rule (pooler.py:121-152)."""
     lib = _lib.load()
     _need_gpu(feats[0].t, "roi_align")
     nl = len(feats)
@@ -661,9 +663,10 @@ def roi_align_ratio(feats: Sequence[View], scales: Sequence[float], boxes: torch
         hs[i], ws_[i] = f.t.shape[1], f.t.shape[2]
         sc[i] = float(scales[i])
     levels = torch.empty((n * topk,), dtype=torch.int32, device=boxes.device)
-    check(lib.cmk_roi_align_ratio(ptrs, hs, ws_, sc, nl, min_level, c, boxes.data_ptr(), counts.data_ptr(), img_area.data_ptr(),
-                                  n, topk, out_size, sampling_ratio, y.data_ptr(), y.shape[3], levels.data_ptr(), _stream()),
-          "cmk_roi_align_ratio")
+    check(lib.cmk_roi_align_pool(ptrs, hs, ws_, sc, nl, min_level, c, boxes.data_ptr(), counts.data_ptr(), img_area.data_ptr(),
+                                 n, topk, out_size, sampling_ratio, int(bool(aligned)), int(bool(assign_by_area)), float(canonical_box_size),
+                                 int(canonical_level), y.data_ptr(), y.shape[3], levels.data_ptr(), _stream()),
+          "cmk_roi_align_pool")
     return levels
 
 

@@ -176,6 +176,14 @@ int cmk_roi_align_ratio(const float* const* feats /* host array of device pointe
                         int N, int topk, int out_size, int sampling_ratio,
                         float* y, int y_cs /* (N*topk, out, out, y_cs) */, int32_t* out_level, void* stream);
 
+/* The general pooler (pooler.py:192-288): aligned = 1 ROIAlignV2 / 0 ROIAlign v1 (torchvision roi_align aligned flag, :243-255);
+ * assign_by_area = 0 the "ratio" rule above / 1 FPN Eqn.(1): floor(canonical_level + log2(sqrt(area) / canonical_box_size + eps))
+ * clamped to the levels (pooler.py:121-152; img_area may then be NULL). */
+int cmk_roi_align_pool(const float* const* feats, const int* feat_h, const int* feat_w, const float* scales, int num_levels, int min_level,
+                       int C, const float* boxes, const int32_t* counts, const float* img_area, int N, int topk, int out_size,
+                       int sampling_ratio, int aligned, int assign_by_area, float canonical_box_size, int canonical_level,
+                       float* y, int y_cs, int32_t* out_level, void* stream);
+
 /* ---- SAG-Mask spatial attention (sam.py:23-28) in place ------------------------------------------------------- */
 int cmk_spatial_attention(float* x /* (R,S,S,C) */, const float* w /* [2][3][3] */, const int32_t* counts, int topk,
                           int R, int S, int C, void* stream);

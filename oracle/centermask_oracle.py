@@ -346,6 +346,16 @@ def assign_boxes_to_levels_by_ratio(boxes: torch.Tensor, img_areas: torch.Tensor
     return lv.to(torch.int64) - min_level
 
 
+def assign_boxes_to_levels(boxes: torch.Tensor, min_level=3, max_level=5, canonical_box_size=224, canonical_level=4):
+    """pooler.py:121-152 (ASSIGN_CRITERION "area", FPN Eqn.(1)): floor(canonical_level + log2(sqrt(area) / canonical_box_size + eps))
+    clamped to [min, max], minus min."""
+    eps = sys.float_info.epsilon
+    box_sizes = torch.sqrt((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]))
+    lv = torch.floor(canonical_level + torch.log2(box_sizes / canonical_box_size + eps))
+    lv = torch.clamp(lv, min=min_level, max=max_level)
+    return lv.to(torch.int64) - min_level
+
+
 def roi_align(feat: torch.Tensor, rois: torch.Tensor, scale: float, out_size: int, sampling_ratio: int, aligned: bool):
     """d2 ROIAlign -> torchvision roi_align CPU kernel (oracle_ops.c:oracle_roi_align)."""
     feat = feat.contiguous().float()
@@ -359,18 +369,22 @@ def roi_align(feat: torch.Tensor, rois: torch.Tensor, scale: float, out_size: in
 
 
 def roi_pooler(features: List[torch.Tensor], boxes_per_image: List[torch.Tensor], image_sizes: List[Tuple[int, int]],
-               scales=(1 / 8, 1 / 16, 1 / 32), out_size=14, sampling_ratio=0):
-    """ROIPooler.forward pooler.py:290-366 with pooler_type ROIAlignV2 and assign_crit "ratio".
-    img_area = image_size[0]*image_size[1] of each Instances (pooler.py:70-77)."""
+               scales=(1 / 8, 1 / 16, 1 / 32), out_size=14, sampling_ratio=0, assign_crit="ratio", aligned=True,
+               canonical_box_size=224, canonical_level=4):
+    """ROIPooler.forward pooler.py:290-366; pooler_type ROIAlignV2 (aligned) or ROIAlign (:243-255), assign_crit "ratio" (:343)
+    or "area".  img_area = image_size[0]*image_size[1] of each Instances (pooler.py:70-77)."""
     rois = torch.cat([torch.cat((torch.full((b.shape[0], 1), float(i)), b), dim=1) for i, b in enumerate(boxes_per_image)], 0)
     img_areas = torch.cat([torch.full((b.shape[0],), float(s[0] * s[1])) for b, s in zip(boxes_per_image, image_sizes)])
     min_level = int(-math.log2(scales[0]))
     max_level = int(-math.log2(scales[-1]))
-    levels = assign_boxes_to_levels_by_ratio(rois[:, 1:], img_areas, min_level, max_level)
+    if assign_crit == "ratio":
+        levels = assign_boxes_to_levels_by_ratio(rois[:, 1:], img_areas, min_level, max_level)
+    else:
+        levels = assign_boxes_to_levels(rois[:, 1:], min_level, max_level, canonical_box_size, canonical_level)
     out = torch.zeros((rois.shape[0], features[0].shape[1], out_size, out_size), dtype=torch.float32)
     for level, (feat, scale) in enumerate(zip(features, scales)):
         inds = torch.nonzero(levels == level).squeeze(1)
-        out[inds] = roi_align(feat, rois[inds], scale, out_size, sampling_ratio, True)
+        out[inds] = roi_align(feat, rois[inds], scale, out_size, sampling_ratio, aligned)
     return out, levels
 
 

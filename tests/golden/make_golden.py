@@ -225,7 +225,21 @@ def main():
         close(ointer["mask_logits"], rlogits, 1e-5, "mask_logits")
         rmiou = roi_heads.maskiou_head(rfeat, torch.cat([r_.pred_masks for r_ in rres]))
         close(ointer["maskiou"], rmiou, 1e-5, "maskiou")
-        out["roi_crafted"] = dict(levels=rlev.clone(), roi_feat=rfeat.clone(), mask_logits=rlogits.clone(), maskiou=rmiou.clone(), **d)
+        # the pooler's other documented modes: level assignment by area (pooler.py:121-152) and ROIAlign v1 (:243-248), reference's own
+        # ROIPooler with canonical size 40 so that the crafted boxes spread over the three levels
+        from centermask.modeling.centermask.pooler import ROIPooler as RefPooler
+        rp = RefPooler(output_size=14, scales=(1 / 8, 1 / 16, 1 / 32), sampling_ratio=0, pooler_type="ROIAlign", canonical_box_size=40,
+                       canonical_level=4, assign_crit="area")
+        rfeat_a = quiet(rp, [ref[k] for k in ("p3", "p4", "p5")], insts)
+        ofeat_a, olev_a = O.roi_pooler([orc[k] for k in ("p3", "p4", "p5")], boxes_per_img, [(H, W)] * 2, assign_crit="area", aligned=False,
+                                       canonical_box_size=40, canonical_level=4)
+        from centermask.modeling.centermask.pooler import assign_boxes_to_levels as ref_assign
+        rlev_a = ref_assign([it.pred_boxes for it in insts], 3, 5, 40, 4)
+        assert torch.equal(rlev_a, olev_a), (rlev_a, olev_a)
+        close(ofeat_a, rfeat_a, 1e-5, "roi_feat area/v1")
+        print("roi crafted levels by area", rlev_a.tolist())
+        out["roi_crafted"] = dict(levels=rlev.clone(), roi_feat=rfeat.clone(), mask_logits=rlogits.clone(), maskiou=rmiou.clone(),
+                                  levels_area=rlev_a.clone(), roi_feat_area_v1=rfeat_a.clone(), **d)
 
         # empty ROI set: the reference leaves mask_scores unset (center_heads.py:513-514)
         e = Instances((H, W))

@@ -95,6 +95,17 @@ def test_roi_heads_crafted_boxes():
         close(res[i]["mask_scores"], g["img{}".format(i)]["mask_scores"], 1e-6)
 
 
+def test_pooler_by_area_and_roialign_v1():
+    g, bb = golden("roi_crafted"), golden("backbone_small")
+    feat, lev = O.roi_pooler([bb[k] for k in ("p3", "p4", "p5")], [g["img0"]["boxes"], g["img1"]["boxes"]], [(64, 96)] * 2, assign_crit="area",
+                             aligned=False, canonical_box_size=40, canonical_level=4)
+    assert torch.equal(lev, g["levels_area"])
+    close(feat, g["roi_feat_area_v1"], 1e-6)
+    # hand-derived: sqrt(area) == canonical size sits exactly on canonical_level; half the size is one level down; clamped at both ends
+    b = torch.tensor([[0., 0., 224., 224.], [0., 0., 112., 112.], [0., 0., 111.9, 112.], [0., 0., 4., 4.], [0., 0., 4000., 4000.]])
+    assert O.assign_boxes_to_levels(b, 2, 5, 224, 4).tolist() == [2, 1, 0, 0, 3]
+
+
 def test_nms_and_level_edge_cases():
     # empty input, single box, duplicate boxes with tied scores (stable: lower index wins)
     e = O.batched_nms(torch.zeros((0, 4)), torch.zeros((0,)), torch.zeros((0,), dtype=torch.int64), 0.6)

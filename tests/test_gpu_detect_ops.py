@@ -206,6 +206,32 @@ def test_roi_heads_match_reference_fixture(dev):
     close(miou, g["maskiou"], 1e-3, "maskiou via reference signature")
 
 
+def test_pooler_by_area_and_roialign_v1_match_reference(dev):
+    """The pooler's other documented modes (pooler.py:121-152 level assignment by area, :243-248 ROIAlign v1 = unaligned) against
+    what the reference's own ROIPooler produced on the crafted boxes (canonical size 40 spreads them over the three levels)."""
+    g, bb = golden("roi_crafted"), golden("backbone_small")
+    feats = [ops.as_view(bb[k].to(dev)) for k in ("p3", "p4", "p5")]
+    k = 7
+    box = torch.zeros((2, k, 4))
+    counts = torch.zeros((2,), dtype=torch.int32)
+    for i in range(2):
+        b = g["img{}".format(i)]["boxes"]
+        box[i, :b.shape[0]], counts[i] = b, b.shape[0]
+    y = torch.empty((2 * k, 14, 14, 256), device=dev)
+    levels = ops.roi_align_ratio(feats, (1 / 8, 1 / 16, 1 / 32), box.to(dev), counts.to(dev), torch.full((2,), 64.0 * 96.0, device=dev), 14, 0, y, 3,
+                                 aligned=False, assign_by_area=True, canonical_box_size=40.0, canonical_level=4)
+    torch.cuda.synchronize()
+    rows = [i * k + j for i in range(2) for j in range(int(counts[i]))]
+    assert torch.equal(levels.cpu()[rows].long(), g["levels_area"])
+    close(y[rows].permute(0, 3, 1, 2), g["roi_feat_area_v1"], 1e-5, "roi_feat (area, v1)")
+    # through the module: cfg POOLER_TYPE ROIAlign + ASSIGN_CRITERION area are accepted (both used to be refused)
+    from centermask2_amd.modeling.centermask.center_heads import ROIPooler
+    p = ROIPooler(14, (1 / 8, 1 / 16, 1 / 32), 0, "ROIAlign", canonical_box_size=40, canonical_level=4, assign_crit="area")
+    assert (p.aligned, p.assign_crit) == (False, "area")
+    with pytest.raises(NotImplementedError):
+        ROIPooler(14, (1 / 8,), 0, "ROIPool")
+
+
 def test_roi_heads_empty_image(dev):
     from .helpers import build_gpu_model
     from centermask2_amd.structures import Boxes, Instances
