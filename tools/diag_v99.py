@@ -1,25 +1,52 @@
-import sys, os
+"""V-99-eSE at 8 x 3x800x1280 (BASELINE config 5's per-GPU workload): how far apart are (a) the CPU oracle on THIS host and the fixture the
+reference produced in the build container, (b) the HIP path and the oracle on this host, (c) both against a float64 run of the oracle
+(the arithmetic's own ground truth).  Prints numbers; the test tolerances in tests/test_gpu_model.py are set from them."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from centermask2_amd import ops, synthetic as S
 from oracle import centermask_oracle as O
-from tests.helpers import build_gpu_model
+from tests.helpers import build_gpu_model, golden, match_detections
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+dev = torch.device("cuda:0")
+g = golden("e2e_v99_800x1280")
 model, sd = build_gpu_model("V-99-eSE")
-x = S.make_synthetic_images(1, 128, 192, seed0=555)
-torch.set_num_threads(16)
+ops.load_tuned(os.path.join(os.path.dirname(ops.__file__), "tuned", "mi355x_V-99-eSE_b8_800x1280.json"))
+x = S.make_synthetic_images(8, 800, 1280, seed0=1234)
+sizes = [(800, 1280)] * 8
 with torch.no_grad():
-    ref_res, ref = O.centermask_inference(sd, x, [(128, 192)], "V-99-eSE", return_intermediates=True)
-    out = model.inference_padded(x.cuda(), [(128, 192)], want=("roi_feat", "levels", "mask_logits", "maskiou"))
-n = 50
-print("levels equal", torch.equal(out["levels"][:n].cpu().long(), ref["levels"]))
-box_err = (out["box"][0, :n].cpu() - ref_res[0]["boxes"]).abs().max(dim=1)[0]
-print("box err max", float(box_err.max()))
-rf = out["roi_feat"][:n].permute(0, 3, 1, 2).cpu(); e = (rf - ref["roi_feat"]).abs().flatten(1).max(dim=1)[0]
-print("roi_feat err per roi (top5)", torch.topk(e, 5))
-cls = ref_res[0]["classes"]
-ml = (out["mask_logits_selected"][:n].cpu() - ref["mask_logits"][torch.arange(n), cls]).abs().flatten(1).max(dim=1)[0]
-print("mask logit err per roi (top5)", torch.topk(ml, 5))
-for k in ("p3", "p4", "p5"):
-    f = model.backbone(x.cuda())[k].cpu(); r = ref["features"][k]
-    err = (f - r).abs()
-    print(k, "max err", float(err.max()), "at", tuple(int(v) for v in torch.nonzero(err == err.max())[0]), "ref there", float(r[tuple(torch.nonzero(err == err.max())[0])]))
+    out = model.inference_padded(x.to(dev), sizes)
+    feats = model.backbone(x.to(dev))
+    lg, reg, ctr, _ = model.proposal_generator.fcos_head([feats[k] for k in ("p3", "p4", "p5", "p6", "p7")])
+torch.cuda.synchronize()
+res = model.results_from_padded(out, sizes)
+t0 = time.time()
+want, wi = O.centermask_inference(sd, x[:1], sizes[:1], "V-99-eSE", return_intermediates=True)
+print("oracle fp32: %.1f s" % (time.time() - t0))
+sd64 = {k: v.double() for k, v in sd.items()}
+t0 = time.time()
+w64, i64 = O.centermask_inference(sd64, x[:1].double(), sizes[:1], "V-99-eSE", return_intermediates=True)
+print("oracle fp64: %.1f s" % (time.time() - t0))
+def rel(a, b): return float((a.double() - b.double()).norm() / b.double().norm())
+def mx(a, b): return float((a.double() - b.double()).abs().max())
+for k in ("p3", "p5", "p7"):
+    print("feature %s: oracle32 vs 64 rel %.2e max %.2e | HIP vs 64 rel %.2e max %.2e | HIP vs oracle32 max %.2e (absmax %.1f)" % (
+        k, rel(wi["features"][k], i64["features"][k]), mx(wi["features"][k], i64["features"][k]), rel(feats[k][:1].cpu(), i64["features"][k]),
+        mx(feats[k][:1].cpu(), i64["features"][k]), mx(feats[k][:1].cpu(), wi["features"][k]), float(i64["features"][k].abs().max())))
+for nm, mine in (("logits", lg), ("bbox_reg", reg), ("ctrness", ctr)):
+    print("%-8s: oracle32 vs 64 max %.2e | HIP vs 64 max %.2e | HIP vs oracle32 max %.2e" % (
+        nm, max(mx(a, b) for a, b in zip(wi[nm], i64[nm])), max(mx(a[:1].cpu(), b) for a, b in zip(mine, i64[nm])), max(mx(a[:1].cpu(), b) for a, b in zip(mine, wi[nm]))))
+r, w, w6, h = g["img0"], want[0], w64[0], res[0]
+for name, a, b in (("host oracle32 vs fixture", w, r), ("host oracle32 vs oracle64", w, w6), ("fixture vs oracle64", r, w6)):
+    try:
+        p = match_detections(a["scores"], a["classes"], a["locations"], b["scores"].float(), b["classes"], b["locations"].float(), tol=1e-3)
+        print("%s: same detections; boxes max %.3e px, scores max %.2e" % (name, mx(a["boxes"], b["boxes"][p]), mx(a["scores"], b["scores"][p])))
+    except AssertionError as e:
+        print(name, "DIFFERENT:", str(e)[:200])
+for name, b in (("oracle32", w), ("oracle64", w6), ("fixture", r)):
+    try:
+        p = match_detections(h.scores, h.pred_classes, h.locations, b["scores"].float(), b["classes"], b["locations"].float(), tol=1e-3)
+        print("HIP vs %s: same detections; boxes max %.3e px, scores max %.2e, order identical %s" % (
+            name, mx(h.pred_boxes.tensor.cpu(), b["boxes"][p]), mx(h.scores.cpu(), b["scores"][p]), bool((p == torch.arange(len(p))).all())))
+    except AssertionError as e:
+        print("HIP vs", name, "DIFFERENT:", str(e)[:200])
