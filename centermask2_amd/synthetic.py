@@ -188,8 +188,20 @@ def synthetic_tensor(name: str, shape: Iterable[int], seed: int = 0) -> torch.Te
 
 
 def make_synthetic_state_dict(conv_body: str = "V-39-eSE", seed: int = 0, shapes=None) -> Dict[str, torch.Tensor]:
+    """Deep bodies (stages of >= 3 OSA blocks: V-57, V-99) get the FrozenBN affine of every identity block's 1x1 aggregation scaled by
+    1/sqrt(blocks in the stage).  Each identity block computes x + eSE(concat(x)); with unit-gain random branches the activations grow
+    geometrically over 9 blocks (V-99: |p3| up to 450) and the fp32 arithmetic of the REFERENCE itself then sits 1.6e-4 (features),
+    2e-3 (logits) and 0.9 px (boxes) away from a float64 evaluation (tools/diag_v99.py) — no fp32 implementation could be compared
+    with it at 1e-3.  A trained network keeps its residual branches small; so does this scaling (|p3| <= 33, fp32 vs fp64 7e-7)."""
+    import re
     shapes = shapes if shapes is not None else model_param_shapes(conv_body)
-    return OrderedDict((k, synthetic_tensor(k, v, seed).float().contiguous()) for k, v in shapes.items())
+    sd = OrderedDict((k, synthetic_tensor(k, v, seed).float().contiguous()) for k, v in shapes.items())
+    blocks = STAGE_SPECS[conv_body]["block_per_stage"]
+    for k in sd:
+        m = re.search(r"stage(\d)\.OSA\d_(\d+)\.concat\..*norm\.(weight|bias)$", k)
+        if m and int(m.group(2)) >= 2 and blocks[int(m.group(1)) - 2] >= 3:
+            sd[k] = (sd[k] * blocks[int(m.group(1)) - 2] ** -0.5).contiguous()
+    return sd
 
 
 def make_synthetic_images(batch: int, height: int = 800, width: int = 1280, seed0: int = 1234,

@@ -25,7 +25,11 @@ want, wi = O.centermask_inference(sd, x[:1], sizes[:1], "V-99-eSE", return_inter
 print("oracle fp32: %.1f s" % (time.time() - t0))
 sd64 = {k: v.double() for k, v in sd.items()}
 t0 = time.time()
-w64, i64 = O.centermask_inference(sd64, x[:1].double(), sizes[:1], "V-99-eSE", return_intermediates=True)
+with torch.no_grad():          # float64 up to the proposals (the ROI kernels of the oracle are float32 C code)
+    f64 = O.backbone_forward(sd64, x[:1].double(), "V-99-eSE")
+    l64, r64, c64 = O.fcos_head_forward(sd64, [f64[k] for k in ("p3", "p4", "p5", "p6", "p7")])
+    p64 = O.fcos_predict_proposals([t.float() for t in l64], [t.float() for t in r64], [t.float() for t in c64])
+w64, i64 = p64, dict(features=f64, logits=l64, bbox_reg=r64, ctrness=c64)
 print("oracle fp64: %.1f s" % (time.time() - t0))
 def rel(a, b): return float((a.double() - b.double()).norm() / b.double().norm())
 def mx(a, b): return float((a.double() - b.double()).abs().max())
