@@ -87,7 +87,8 @@ def test_thresh_with_ctr_and_large_topk_vs_oracle(dev, topk):
     shapes = [(25, 40), (13, 20), (7, 10), (4, 5), (2, 3)]
     logits, reg, ctr = _crafted_levels(2, shapes, 11, -2.5)
     for with_ctr in (False, True):
-        cand, det = _run_detect(logits, reg, ctr, dev, topk=topk, with_ctr=with_ctr)
+        cand, det = _run_detect(logits, reg, ctr, dev, cap=131072, topk=topk, with_ctr=with_ctr)     # ~68k candidates per image: also the >= 40000 per-class NMS branch
+        assert int(cand["counts"].max()) <= 131072
         oprops, ocands = O.fcos_predict_proposals(logits, reg, ctr, post_nms_topk=topk, return_candidates=True, thresh_with_ctr=with_ctr)
         for i in range(2):
             assert int(cand["counts"][i]) == ocands[i]["scores"].shape[0]
