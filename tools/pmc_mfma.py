@@ -16,11 +16,14 @@ from centermask2_amd.ops import kernel_source_hash
 
 rows = collections.defaultdict(dict)
 names = {}
+dur_csv = {}
 for r in csv.DictReader(open(sys.argv[1])):
     did = r.get("Dispatch_Id") or r.get("Dispatch_ID")
     rows[did][r["Counter_Name"]] = float(r["Counter_Value"])
     names[did] = r["Kernel_Name"].replace("void cmk::", "").replace("(cmk::ConvArgs)", "")
-dur = {}
+    if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+        dur_csv[did] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+dur = dict(dur_csv)
 if len(sys.argv) > 3:
     for r in csv.DictReader(open(sys.argv[3])):
         dur[r.get("Dispatch_Id") or r.get("Dispatch_ID")] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
