@@ -10,10 +10,10 @@ mkdir -p $OUT $ROOT/profiles
 export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
 cd /tmp
-echo "== kernel trace + stats"; rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python3 $ROOT/bench.py $ARGS > $OUT/bench_under_stats.json 2> $OUT/stats.err || tail -3 $OUT/stats.err
-echo "== pmc mfma";  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o m -- python3 $ROOT/bench.py $ARGS > $OUT/bench_under_mfma.json 2> $OUT/mfma.err || tail -3 $OUT/mfma.err
-echo "== pmc fetch"; rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/fetch.err || tail -3 $OUT/fetch.err
-echo "== pmc write"; rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/write.err || tail -3 $OUT/write.err
+echo "== kernel trace + stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $ROOT/bench.py $ARGS > $OUT/bench_under_stats.json 2> $OUT/stats.err || tail -3 $OUT/stats.err
+echo "== pmc mfma";  rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o m -- python3 $ROOT/bench.py $ARGS > $OUT/bench_under_mfma.json 2> $OUT/mfma.err || tail -3 $OUT/mfma.err
+echo "== pmc fetch"; rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/fetch.err || tail -3 $OUT/fetch.err
+echo "== pmc write"; rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/write -o w -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/write.err || tail -3 $OUT/write.err
 cd $ROOT
 find $OUT -name "*.csv" | head -20
 ST=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$ST" ] && head -40 $ST > profiles/${TAG}_bench_kernel_stats.csv
