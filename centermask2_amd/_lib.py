@@ -4,7 +4,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcmk_hip.so")
+LIB_PATH = os.environ.get("CMK_LIB") or os.path.join(_HERE, "libcmk_hip.so")      # CMK_LIB: an alternative build (A/B tooling, tools/ab)
 _lib = None
 
 

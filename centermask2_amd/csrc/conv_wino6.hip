@@ -32,6 +32,9 @@
 // sam.py:58-70, maskiou_head.py:81-88).
 #include "conv_args.hpp"
 
+#ifndef W6_TRACE_EVERY
+#define W6_TRACE_EVERY 16
+#endif
 #ifndef W6_ABL
 #define W6_ABL 0     // timing ablations (tools/ab): 1 no pass 1, 2 no halo loads, 4 no weight loads, 8 no barrier — results are wrong with any set
 #endif
@@ -78,21 +81,38 @@ __device__ __forceinline__ int w6_slot(int q, int t, int a, int col) {
     return q * W6_QP + t * W6_TP + a * W6_AP + (col & 3) * 12 + (col >> 2);
 }
 
-// one half of the 1-D input transform (B^T rows 0-2 or 3-5) on five consecutive samples x0..x4 (= d0..d4 for the first half, d1..d5 for
-// the second):   first:  4x0-5x2+x4, (x4-4x2)+(x3-4x1), (x4-4x2)-(x3-4x1)      second: (x3-x1)+2(x2-x0), (x3-x1)-2(x2-x0), 4x0-5x2+x4
-template <typename T>
-__device__ __forceinline__ void w6_half_first(const T x0, const T x1, const T x2, const T x3, const T x4, T& v0, T& v1, T& v2) {
-    const T p = x4 - 4.0f * x2, q = x3 - 4.0f * x1;
-    v0 = 4.0f * x0 + (x4 - 5.0f * x2);
-    v1 = p + q;
-    v2 = p - q;
+// Packed-fp32 arithmetic spelled out.  The transforms are the minimal sequences of v_pk_* instructions (6 per half transform of two
+// channels); left to the compiler the same formulas came out as a mix of scalar FMAs, sign flips (v_xor) and register moves — 5.5 VALU
+// instructions per MFMA instead of 1.5.  One asm block per half transform: the compiler cannot see what kind of instruction wrote the
+// results, so it cannot keep its own distance rules between a VALU write and the MFMA / LDS store that reads it (built from single-
+// instruction asm statements the kernel computed garbage as soon as the scheduler moved them); the block ends with the wait states itself.
+//   first  (B^T rows 0-2 on x0..x4 = d0..d4):  v0 = 4x0 - 5x2 + x4,  v1 = (x4 - 4x2) + (x3 - 4x1),  v2 = (x4 - 4x2) - (x3 - 4x1)
+//   second (B^T rows 3-5 on x0..x4 = d1..d5):  v0 = (x3 - x1) + 2(x2 - x0),  v1 = (x3 - x1) - 2(x2 - x0),  v2 = 4x0 - 5x2 + x4
+__device__ __forceinline__ void w6_half_first(const f32x2 x0, const f32x2 x1, const f32x2 x2, const f32x2 x3, const f32x2 x4, const f32x2 five,
+                                              f32x2& v0, f32x2& v1, f32x2& v2) {
+    f32x2 p, q;
+    asm volatile("v_pk_fma_f32 %0, %7, %10, %9 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"      // v0 = x4 - 5 x2
+                 "v_pk_fma_f32 %3, %7, 4.0, %9 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"       // p  = x4 - 4 x2
+                 "v_pk_fma_f32 %4, %6, 4.0, %8 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"       // q  = x3 - 4 x1
+                 "v_pk_fma_f32 %0, %5, 4.0, %0 op_sel_hi:[1,0,1]\n\t"                                      // v0 += 4 x0
+                 "v_pk_add_f32 %1, %3, %4\n\t"                                                             // v1 = p + q
+                 "v_pk_add_f32 %2, %3, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"                                   // v2 = p - q
+                 "s_nop 1"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(p), "=&v"(q)
+                 : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "s"(five));
 }
-template <typename T>
-__device__ __forceinline__ void w6_half_second(const T x0, const T x1, const T x2, const T x3, const T x4, T& v0, T& v1, T& v2) {
-    const T r = x3 - x1, s = 2.0f * (x2 - x0);
-    v0 = r + s;
-    v1 = r - s;
-    v2 = 4.0f * x0 + (x4 - 5.0f * x2);
+__device__ __forceinline__ void w6_half_second(const f32x2 x0, const f32x2 x1, const f32x2 x2, const f32x2 x3, const f32x2 x4, const f32x2 five,
+                                               f32x2& v0, f32x2& v1, f32x2& v2) {
+    f32x2 r, t;
+    asm volatile("v_pk_add_f32 %3, %8, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"                                   // r  = x3 - x1
+                 "v_pk_add_f32 %4, %7, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"                                   // t  = x2 - x0
+                 "v_pk_fma_f32 %2, %7, %10, %9 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"      // v2 = x4 - 5 x2
+                 "v_pk_fma_f32 %0, %4, 2.0, %3 op_sel_hi:[1,0,1]\n\t"                                      // v0 = r + 2t
+                 "v_pk_fma_f32 %1, %4, 2.0, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"       // v1 = r - 2t
+                 "v_pk_fma_f32 %2, %5, 4.0, %2 op_sel_hi:[1,0,1]\n\t"                                      // v2 += 4 x0
+                 "s_nop 1"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(r), "=&v"(t)
+                 : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "s"(five));
 }
 
 // AFF: the producer's GroupNorm+ReLU is applied to the input in pass 1 (FCOS tower convs 2-4 and the predictors)
@@ -150,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     }
     const float* aff_s = AFF ? P.in_scale + (long)n * a.Cin + p_q * 4 : nullptr;
     const float* aff_b = AFF ? P.in_shift + (long)n * a.Cin + p_q * 4 : nullptr;
+    const f32x2 five = {5.0f, 5.0f};                   // the one transform coefficient that is not an inline constant: an SGPR pair
     f32x4 d[6];
     f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
     auto load_D = [&](int chunk) {
@@ -173,12 +194,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
                 d[i] = v;
             }
         }
-        f32x4 w0, w1, w2, w3, w4, w5;
-        w6_half_first(d[0], d[1], d[2], d[3], d[4], w0, w1, w2);
-        w6_half_second(d[1], d[2], d[3], d[4], d[5], w3, w4, w5);
-        f32x4* dst = wbuf + p_dst;
-        dst[0 * W6_AP] = w0; dst[1 * W6_AP] = w1; dst[2 * W6_AP] = w2;
-        dst[3 * W6_AP] = w3; dst[4 * W6_AP] = w4; dst[5 * W6_AP] = w5;
+        f32x2* dst = reinterpret_cast<f32x2*>(wbuf + p_dst);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                 // channel pairs: 12 packed instructions and 6 ds_write_b64 each
+            f32x2 e[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) e[i] = h ? f32x2{d[i].z, d[i].w} : f32x2{d[i].x, d[i].y};
+            f32x2 w0, w1, w2, w3, w4, w5;
+            w6_half_first(e[0], e[1], e[2], e[3], e[4], five, w0, w1, w2);
+            w6_half_second(e[1], e[2], e[3], e[4], e[5], five, w3, w4, w5);
+            dst[0 * 2 * W6_AP + h] = w0; dst[1 * 2 * W6_AP + h] = w1; dst[2 * 2 * W6_AP + h] = w2;
+            dst[3 * 2 * W6_AP + h] = w3; dst[4 * 2 * W6_AP + h] = w4; dst[5 * 2 * W6_AP + h] = w5;
+        }
     };
 
     // ---- MFMA side -------------------------------------------------------------------------------------------------------------
@@ -192,28 +219,46 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     const f32x4* wB = wl + rowB * W6_AP;
     // U image: [chunk][cout tile][wave][9 slots][lane 64][4 floats]; slot k < 6: frequency (rowA, k); k >= 6: (rowB, 3*halfB + k - 6);
     // lane = 32*hh + li holds channels 8*chunk + 4*hh .. +3 of output channel 32*tile + li
-    const float* u_lane = a.w + ((long)by * 4 + wave) * (9 * 256) + lane * 4;
+    const float* u_wave = a.w + ((long)by * 4 + wave) * (9 * 256);       // wave-uniform: the loads take it as a scalar base, lane * 16 B as offset
     const long u_chunk = (long)a.grid_y * (36 * 256);
+    const int u_lane_off = lane * 4;
     f32x4 ub[3][3];
     auto load_U = [&](int step, int buf) {          // step = chunk*3 + s
 #if W6_ABL & 4
         if (step > 2) return;
 #endif
         const int c = step / 3, s = step - c * 3;
-        const float* src = u_lane + c * u_chunk + s * (3 * 256);
+        const float* src = u_wave + c * u_chunk + s * (3 * 256);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ub[buf][k] = *reinterpret_cast<const f32x4*>(src + k * 256);
+        for (int k = 0; k < 3; ++k) ub[buf][k] = *reinterpret_cast<const f32x4*>(src + (u_lane_off + k * 256));
     };
     const int total_steps = nchunks * 3;
 
 #ifdef W6_TRACE
     // instrumented build (tools/ab/trace_wino6.py): lane 0 of every wave of every 16th workgroup stamps the shader clock into a.ws
-    unsigned long long* trc = (a.ws && (blockIdx.x & 15) == 0 && lane == 0) ? reinterpret_cast<unsigned long long*>(a.ws) + ((blockIdx.x >> 4) * 4 + wave) * 64 : nullptr;
+    unsigned long long* trc = (a.ws && (blockIdx.x % W6_TRACE_EVERY) == 0 && lane == 0) ? reinterpret_cast<unsigned long long*>(a.ws) + ((blockIdx.x / W6_TRACE_EVERY) * 4 + wave) * 64 : nullptr;
     int trn = 0;
 #define W6_STAMP() do { if (trc) { trc[trn] = __builtin_readcyclecounter(); } ++trn; } while (0)
-    if (trc) trc[63] = __builtin_amdgcn_s_memrealtime();
+    if (trc) {
+        trc[63] = __builtin_amdgcn_s_memrealtime();
+        trc[61] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));       // HW_REG_HW_ID (wave slot, SIMD, CU, SH, SE)
+        trc[60] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((32 - 1) << 11));      // HW_REG_XCC_ID
+    }
 #else
 #define W6_STAMP() do { } while (0)
+#endif
+#ifdef W6_STAGGER
+    // Two workgroups share a CU and, launched together with equal work, stay in lock-step for the whole launch: both in their prologue,
+    // both in their loop, both in their epilogue — nothing covers the ~25 % of a workgroup's life in which it feeds the matrix pipe
+    // nothing (tools/ab/trace_wino6.py).  Delay the second one ONCE, at launch, by about half a workgroup life; every later workgroup
+    // starts when its predecessor on the same slot ends and inherits the phase.  Which of the two a wave belongs to: the wave slot
+    // it got in its SIMD (HW_ID.WAVE_ID, bits 3:0) — the first resident workgroup holds slot 0, the second slot 1.  Nothing depends on
+    // this for correctness.
+    if (blockIdx.x < 512 && a.stagger_sleeps > 0) {
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));      // HW_REG_HW_ID, offset 0, 4 bits
+        if (hw_id & 1u)
+            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);            // ~8100 cycles each
+    }
 #endif
     W6_STAMP();                                       // 0: start
     // ---- prologue ----------------------------------------------------------------------------------------------------------------
@@ -275,14 +320,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     // one half-step = 6 MFMAs: transform the samples read during the previous half-step, issue the MFMAs
     auto half_step = [&](const X5& x, bool second, int h, int sbuf, int abase) {
         f32x2 v0, v1, v2;
-        if (!second) w6_half_first(x.x0, x.x1, x.x2, x.x3, x.x4, v0, v1, v2);
-        else w6_half_second(x.x0, x.x1, x.x2, x.x3, x.x4, v0, v1, v2);
+        if (!second) w6_half_first(x.x0, x.x1, x.x2, x.x3, x.x4, five, v0, v1, v2);
+        else w6_half_second(x.x0, x.x1, x.x2, x.x3, x.x4, five, v0, v1, v2);
         mm(v0, v1, v2, h, sbuf, abase);
     };
     auto half_stepB = [&](const X5& x, int h) {      // MFMAs stay outside the branch: on both sides of one the allocator keeps two
         f32x2 v0, v1, v2;                           // copies of the accumulators they touch
-        if (halfB == 0) { asm volatile("" ::: "memory"); w6_half_first(x.x0, x.x1, x.x2, x.x3, x.x4, v0, v1, v2); }
-        else            { asm volatile("" ::: "memory"); w6_half_second(x.x0, x.x1, x.x2, x.x3, x.x4, v0, v1, v2); }
+        if (halfB == 0) { asm volatile("" ::: "memory"); w6_half_first(x.x0, x.x1, x.x2, x.x3, x.x4, five, v0, v1, v2); }
+        else            { asm volatile("" ::: "memory"); w6_half_second(x.x0, x.x1, x.x2, x.x3, x.x4, five, v0, v1, v2); }
         mm(v0, v1, v2, h, 2, 6);
     };
     W6_STAMP();                                       // 1: prologue done
@@ -297,30 +342,42 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
         if (c < 40) W6_STAMP();                       // 2 + c: period c entered
 #endif
         // the LDS reads of half-step k+1 are issued in front of the MFMAs of half-step k: their latency hides under the 6 MFMAs
+#ifdef W6_TRACE
+#define W6_STAMP_AT(slot) do { if (trc && c == 8) trc[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W6_STAMP_AT(slot) do { } while (0)
+#endif
+        W6_STAMP_AT(50);
         load_U(min(step + 2, total_steps - 1), 2);
         X5 xa = rd(wA + wcur, false, 0);
         X5 xb = rd(wA + wcur, false, 1);
         half_step(xa, false, 0, 0, 0);
+        W6_STAMP_AT(51);                              // after reads + transform + 6 MFMAs issued
         xa = rd(wA + wcur, true, 0);
         half_step(xb, false, 1, 0, 0);
+        W6_STAMP_AT(52);                              // step 0 issued
         W6_FENCE;
 #if !(W6_ABL & 1)
         pass1(wnext);
 #endif
+        W6_STAMP_AT(53);                              // pass 1 done (LDS writes issued)
 #if !(W6_ABL & 2)
         load_D(min(c + 2, nchunks - 1));
 #endif
+        W6_STAMP_AT(54);                              // halo loads issued
         W6_FENCE;
         load_U(min(step + 3, total_steps - 1), 0);
         xb = rd(wA + wcur, true, 1);
         half_step(xa, true, 0, 1, 3);
         xa = rdB(wB + wcur, 0);
         half_step(xb, true, 1, 1, 3);
+        W6_STAMP_AT(55);                              // step 1 issued
         W6_FENCE;
         load_U(min(step + 4, total_steps - 1), 1);
         xb = rdB(wB + wcur, 1);
         half_stepB(xa, 0);
         half_stepB(xb, 1);
+        W6_STAMP_AT(56);                              // step 2 issued
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------------------
@@ -487,6 +544,13 @@ int launch_wino6(ConvArgs& a, hipStream_t st) {
     }
     a.grid_y = cdiv(a.Cout, 32);
     a.total_tiles = blocks;
+#ifdef W6_STAGGER
+    {   // half a workgroup life in units of s_sleep 127 (~4.2 us): life ~ 14 us + 3.3 us per 8-channel chunk; only where the launch
+        // is long enough (>= 4 rounds of 512 workgroups) for the one-off delay to pay
+        const long wgs = (long)blocks * a.grid_y;
+        a.stagger_sleeps = wgs >= 4 * 512 ? (int)((14.0 + 3.3 * (a.Cin >> 3)) / 2.0 / 4.2 + 0.5) : 0;
+    }
+#endif
     const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y);
     if (a.p[0].in_scale)
         hipLaunchKernelGGL(conv_wino6_kernel<true>, grid, dim3(256), W6_LDS_ALLOC, st, a);

@@ -46,5 +46,10 @@ print("loop-end barrier    %.2f us" % us(t[:, :, 43] - t[:, :, 42]))
 print("round 0 write %.2f | barrier %.2f | finish+store %.2f us" % (us(t[:, :, 44] - t[:, :, 43]), us(t[:, :, 45] - t[:, :, 44]), us(t[:, :, 46] - t[:, :, 45])))
 print("round 1 write %.2f | barrier %.2f | finish+store %.2f us" % (us(t[:, :, 47] - t[:, :, 46]), us(t[:, :, 48] - t[:, :, 47]), us(t[:, :, 49] - t[:, :, 48])))
 print("epilogue total      %.2f us; loop total %.2f us; life %.2f us" % (us(t[:, :, 49] - t[:, :, 42]), us(t[:, :, 42] - t[:, :, 2]), us(life)))
+if t[:, :, 50].min() > 0:
+    names = ["barrier -> half-step 0 issued (reads, transform, 6 MFMAs)", "half-step 1 issued", "pass 1 (wait halo, transform, LDS writes)", "halo loads issued",
+             "step 1 issued (12 MFMAs)", "step 2 issued (12 MFMAs)"]
+    print("inside period 8 (cycles, median over waves): " + "; ".join("%s %.0f" % (nm, np.median(t[:, :, 51 + i] - t[:, :, 50 + i])) for i, nm in enumerate(names)))
+    print("   period-8 total stamped %.0f cycles" % np.median(t[:, :, 56] - t[:, :, 50]))
 # how the workgroups of one CU overlap cannot be read from here; the launch time / rounds gives the per-slot life:
 print("launch time / (workgroups / 512 slots) = %.1f us per slot-life" % (e0.elapsed_time(e1) * 1e3 / (nwg / 512.0)))
