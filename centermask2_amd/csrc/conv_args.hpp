@@ -55,6 +55,6 @@ struct DeviceOnce {
 };
 
 // conv_wino6.hip: fused Winograd F(4x4,3x3)
-int launch_wino6(ConvArgs& a, hipStream_t st);
+int launch_wino6(ConvArgs& a, int geo, hipStream_t st);
 
 }  // namespace cmk

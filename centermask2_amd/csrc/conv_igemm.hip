@@ -929,7 +929,8 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         }
         a.w = d->w_wino6;
         a.ws = d->splitk_ws;          // instrumented builds (W6_TRACE) only: a stamp buffer; unused otherwise
-        return launch_wino6(a, st);
+        if (d->tune_wn != 1 && d->tune_wn != 2) return fail(CMK_EINVAL, "conv: tune_wm 6 takes tune_wn 1 (12x40 map tiles) or 2 (pairs of RoI maps up to 16x14)%s", "");
+        return launch_wino6(a, d->tune_wn == 2 ? 1 : 0, st);
     }
     a.ksplit = d->splitk > 1 ? d->splitk : 1;
     a.ws = d->splitk_ws;
@@ -963,13 +964,18 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
                 covered += (double)t * 480.0;
                 wgs += t * cdiv(d->Cout, 32);
             }
+            // maps of at most 16 x 14 (the 14x14 RoI features): two whole maps per workgroup instead of 12x40 tiles that would be 20 % full
+            if (n == 1 && d->H <= 16 && d->W <= 14 && !d->gn_ws && (long)cdiv(d->N, 2) * cdiv(d->Cout, 32) >= 256) {
+                a.w = d->w_wino6;
+                return launch_wino6(a, 1, st);
+            }
             if (px >= 0.55 * covered && wgs >= 256) {
                 if (d->gn_ws) {
                     int rc = setup_gn(a, d);
                     if (rc) return rc;
                 }
                 a.w = d->w_wino6;
-                return launch_wino6(a, st);
+                return launch_wino6(a, 0, st);
             }
         }
         if (d->ksize == 3 && d->stride == 1 && d->res_mode == 0 && !d->in_relu && d->w_wino && d->Cin >= 32 && d->splitk <= 1) {

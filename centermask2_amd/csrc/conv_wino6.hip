@@ -52,33 +52,51 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // bounds-checked 16-byte load: lanes whose byte offset lies outside [0, num_records) of the resource get 0
 __device__ f32x4 w6_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
-constexpr int W6_TR = 3, W6_TC = 10;                   // tiles of 4x4 outputs per workgroup
-constexpr int W6_OH = 4 * W6_TR, W6_OW = 4 * W6_TC;    // 12 x 40 output pixels
-constexpr int W6_HC = W6_OW + 2;                       // 42 halo columns
-constexpr int W6_ITEMS = W6_TR * W6_HC * 2;            // pass-1 items: (tile row, halo column, channel quad) = 252
-constexpr int W6_AP = 48;                              // W image pitches in 16-byte slots: grid row a
-constexpr int W6_TP = 6 * W6_AP + 10;                  //   tile row t: == 10 (mod 16), see w6_slot
-constexpr int W6_QP = W6_TR * W6_TP;                   //   channel quad
-constexpr int W6_WB = 2 * W6_QP;                       // one W buffer = 1788 slots
+// Two tilings of the 32 MFMA rows (a workgroup's 32 tiles of 4x4 outputs):
+//   GEO 0  maps: 3 x 10 tiles of ONE image (12 x 40 pixels: every map width of the model is a multiple of 40); rows 30, 31 carry no tile;
+//   GEO 1  RoI maps (at most 16 rows x 14 columns, e.g. the 14x14 RoI features of the mask / mask-IoU heads): 4 x 4 tiles of each of
+//          TWO consecutive images; halo columns 15..17 (image columns >= 14) are zero by construction, so their W slots are cleared
+//          once and only 15 columns go through pass 1: 2 x (4 x 15 x 2) = 240 items, waves 0-1 image 0, waves 2-3 image 1.
+// W image, in 16-byte slots: entry (channel quad q, row group r, grid row a, halo column col) lives at
+//   q*QP + r*TP + a*AP + (col & 3)*CK + (col >> 2)          r = tile row (GEO 0) or 4*image + tile row (GEO 1)
+// A lane of the MFMA side is tile m and reads col = 4*tc + j, i.e. slot = const + r*TP + tc (+1 for j >= 4).  A ds_read_b128 is served
+// in groups of 16 lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} per half wave; TP is chosen modulo 16 (10 for GEO 0, 4 for GEO 1) so that
+// the tiles of either group fall on 16 distinct slots modulo 16, whatever a and j are: conflict-free without padding the rows.
+template <int GEO> struct W6G;
+template <> struct W6G<0> {
+    static constexpr int OH = 12, OW = 40, HC = 42, CK = 12, AP = 48, TP = 6 * 48 + 10, RG = 3, QP = RG * TP, WB = 2 * QP;
+    static constexpr int ITEMS = 3 * HC * 2;                // 252: (tile row, halo column, channel quad)
+    static constexpr int TILES = 30;
+    __device__ static __forceinline__ void tile_of(int m, int& img, int& t, int& tc) { img = 0; t = (m * 205) >> 11; tc = m - t * 10; }      // m / 10, m < 32
+    __device__ static __forceinline__ void item_of(int tid, int& img, int& q, int& t, int& col, bool& active) {
+        const int i = min(tid, ITEMS - 1);                 // threads 252..255 repeat the last item (same values, same slots)
+        img = 0; q = i & 1; const int cc = i >> 1; t = cc / HC; col = cc - t * HC; active = true;
+    }
+};
+template <> struct W6G<1> {
+    static constexpr int OH = 16, OW = 14, HC = 15, CK = 5, AP = 20, TP = 6 * 20 + 12, RG = 8, QP = RG * TP, WB = 2 * QP;
+    static constexpr int ITEMS = 256;
+    static constexpr int TILES = 32;
+    __device__ static __forceinline__ void tile_of(int m, int& img, int& t, int& tc) { img = m >> 4; t = (m >> 2) & 3; tc = m & 3; }
+    __device__ static __forceinline__ void item_of(int tid, int& img, int& q, int& t, int& col, bool& active) {
+        img = tid >> 7; const int i = tid & 127; active = i < 4 * HC * 2;
+        const int j = min(i, 4 * HC * 2 - 1); q = j & 1; const int cc = j >> 1; t = cc / HC; col = cc - t * HC;
+    }
+};
 constexpr int W6_EX_FLOATS = 4 * 4 * 2 * 8 * 64;       // epilogue exchange: [src wave][dst wave][reg of the round][value][lane] = 64 KiB
-constexpr int W6_LDS_BYTES = (2 * W6_WB * 16 > W6_EX_FLOATS * 4) ? 2 * W6_WB * 16 : W6_EX_FLOATS * 4;   // loop 57,216, exchange 65,536: two workgroups per CU
+template <int GEO> constexpr int w6_lds_bytes() { return (2 * W6G<GEO>::WB * 16 > W6_EX_FLOATS * 4) ? 2 * W6G<GEO>::WB * 16 : W6_EX_FLOATS * 4; }
 #ifdef W6_ONE_WG     // experiment: one workgroup per CU (how fast is a workgroup without a partner?)
-#undef W6_LDS_DECL
-constexpr int W6_LDS_ALLOC = 96 * 1024;
+template <int GEO> constexpr int w6_lds_alloc() { return 96 * 1024; }
 #else
-constexpr int W6_LDS_ALLOC = W6_LDS_BYTES;
-static_assert(2 * W6_LDS_BYTES <= LDS_CU, "two workgroups per CU");
+template <int GEO> constexpr int w6_lds_alloc() { return w6_lds_bytes<GEO>(); }
+static_assert(2 * w6_lds_bytes<0>() <= LDS_CU && 2 * w6_lds_bytes<1>() <= LDS_CU, "two workgroups per CU");
 #endif
-static_assert(W6_ITEMS <= 256, "one pass-1 item per thread");
+static_assert(W6G<0>::TP % 16 == 10 && W6G<1>::TP % 16 == 4, "conflict-free W image");
 
-// W image, in 16-byte slots: entry (channel quad q, tile row t, grid row a, halo column col) lives at
-//   q*QP + t*TP + a*AP + (col & 3)*12 + (col >> 2)
-// A lane of the MFMA side is tile m = 10*t + tc and reads col = 4*tc + j, i.e. slot = const + t*TP + tc (+1 for j >= 4).  A
-// ds_read_b128 is served in groups of 16 lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} per half wave; with TP == 10 (mod 16) the tiles
-// of either group fall on 16 distinct slots modulo 16 (t = 0: tc, t = 1: 10 + tc, t = 2: 4 + tc; lanes 30, 31 carry no tile and read
-// the two slots that are left), whatever a and j are: conflict-free without padding the rows.
-__device__ __forceinline__ int w6_slot(int q, int t, int a, int col) {
-    return q * W6_QP + t * W6_TP + a * W6_AP + (col & 3) * 12 + (col >> 2);
+template <int GEO>
+__device__ __forceinline__ int w6_slot(int q, int r, int a, int col) {
+    using G = W6G<GEO>;
+    return q * G::QP + r * G::TP + a * G::AP + (col & 3) * G::CK + (col >> 2);
 }
 
 // Packed-fp32 arithmetic spelled out.  The transforms are the minimal sequences of v_pk_* instructions (6 per half transform of two
@@ -116,8 +134,10 @@ __device__ __forceinline__ void w6_half_second(const f32x2 x0, const f32x2 x1, c
 }
 
 // AFF: the producer's GroupNorm+ReLU is applied to the input in pass 1 (FCOS tower convs 2-4 and the predictors)
-template <bool AFF>
+template <bool AFF, int GEO>
 __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
+    using G = W6G<GEO>;
+    constexpr int W6_AP = G::AP, W6_WB = G::WB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* sW = reinterpret_cast<f32x4*>(smem);
 
@@ -137,25 +157,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     const ConvProblem& P = a.p[pi];
     const int H = P.H, W = P.W;
     const int tile = bx - P.tile_begin;
-    const int tw = tile % P.tiles_w;
-    const int t2 = tile / P.tiles_w;
-    const int th = t2 % P.tiles_h;
-    const int n = t2 / P.tiles_h;
-    const int oh0 = th * W6_OH, ow0 = tw * W6_OW;
+    int n, oh0, ow0;
+    if (GEO == 0) {
+        const int tw = tile % P.tiles_w;
+        const int t2 = tile / P.tiles_w;
+        const int th = t2 % P.tiles_h;
+        n = t2 / P.tiles_h;
+        oh0 = th * G::OH; ow0 = tw * G::OW;
+    } else {                      // a pair of whole images
+        n = tile * 2; oh0 = 0; ow0 = 0;
+    }
     const int co0 = by * 32;
     const int nchunks = a.Cin >> 3;
 
     // ---- pass 1 item of this thread ----------------------------------------------------------------------------------------------
-    const int p_item = min(tid, W6_ITEMS - 1);                     // threads 252..255 repeat the last item (same values, same slots)
-    const int p_q = p_item & 1, p_cc = p_item >> 1;
-    const int p_t = p_cc / W6_HC, p_col = p_cc - p_t * W6_HC;
-    // buffer resource over image n: {base, num_records = bytes of the image, raw dword format}
+    int p_img, p_q, p_t, p_col;
+    bool p_active;
+    G::item_of(tid, p_img, p_q, p_t, p_col, p_active);
+    // buffer resource over the image this thread stages (GEO 1: wave-uniform, waves 0-1 the first image of the pair, waves 2-3 the second;
+    // an image index past the batch gets an empty resource: every load returns 0): {base, num_records = bytes of the image, raw dword format}
     i32x4 rsrc;
     {
-        const unsigned long long base = (unsigned long long)(P.x + (long)n * H * W * a.x_cs);
+        const int img_n = n + (GEO == 1 ? (wave >> 1) : 0);
+        const unsigned long long base = (unsigned long long)(P.x + (long)min(img_n, P.N - 1) * H * W * a.x_cs);
         rsrc.x = __builtin_amdgcn_readfirstlane((int)(base & 0xffffffffull));
         rsrc.y = __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffull));
-        rsrc.z = __builtin_amdgcn_readfirstlane(H * W * a.x_cs * 4);
+        rsrc.z = __builtin_amdgcn_readfirstlane(img_n < P.N ? H * W * a.x_cs * 4 : 0);
         rsrc.w = 0x00020000;
     }
     const int row_bytes = W * a.x_cs * 4;
@@ -168,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) okm |= ((iw >= 0 && iw < W && ih0 + i >= 0 && ih0 + i < H) ? 1u : 0u) << i;
     }
-    const float* aff_s = AFF ? P.in_scale + (long)n * a.Cin + p_q * 4 : nullptr;
-    const float* aff_b = AFF ? P.in_shift + (long)n * a.Cin + p_q * 4 : nullptr;
+    const float* aff_s = AFF ? P.in_scale + (long)min(n + p_img, P.N - 1) * a.Cin + p_q * 4 : nullptr;
+    const float* aff_b = AFF ? P.in_shift + (long)min(n + p_img, P.N - 1) * a.Cin + p_q * 4 : nullptr;
     const f32x2 five = {5.0f, 5.0f};                   // the one transform coefficient that is not an inline constant: an SGPR pair
     f32x4 d[6];
     f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
@@ -181,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
             in_sh = *reinterpret_cast<const f32x4*>(aff_b + chunk * 8);
         }
     };
-    const int p_dst = w6_slot(p_q, p_t, 0, p_col);
+    const int p_dst = w6_slot<GEO>(p_q, (GEO == 1 ? 4 * p_img : 0) + p_t, 0, p_col);
     auto pass1 = [&](f32x4* wbuf) {
         if (AFF) {
 #pragma unroll
@@ -195,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
             }
         }
         f32x2* dst = reinterpret_cast<f32x2*>(wbuf + p_dst);
+        if (GEO == 1 && !p_active) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                 // channel pairs: 12 packed instructions and 6 ds_write_b64 each
             f32x2 e[6];
@@ -213,8 +241,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     // stored); lane half hh = channel quad; accumulator register r of lane half hh is tile m = (r & 3) + 8*(r >> 2) + 4*hh, column
     // li = output channel co0 + li
     const int rowA = wave, rowB = 4 + (wave >> 1), halfB = wave & 1;
-    const int m_t = li / W6_TC, m_tc = li - m_t * W6_TC;
-    const f32x4* wl = sW + w6_slot(hh, m_t, 0, 4 * m_tc);
+    int m_img, m_t, m_tc;
+    G::tile_of(li, m_img, m_t, m_tc);
+    const f32x4* wl = sW + w6_slot<GEO>(hh, (GEO == 1 ? 4 * m_img : 0) + m_t, 0, 4 * m_tc);
     const f32x4* wA = wl + rowA * W6_AP;
     const f32x4* wB = wl + rowB * W6_AP;
     // U image: [chunk][cout tile][wave][9 slots][lane 64][4 floats]; slot k < 6: frequency (rowA, k); k >= 6: (rowB, 3*halfB + k - 6);
@@ -260,6 +289,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
             for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);            // ~8100 cycles each
     }
 #endif
+    if (GEO == 1) {
+        // halo columns 15..17 (image columns >= 14) are zero for every image this geometry accepts: their W slots are cleared here, once,
+        // in both buffers, and pass 1 never touches them
+        for (int i = tid; i < 2 * 2 * G::RG * 6 * 3; i += 256) {
+            const int c3 = i % 3, rest = i / 3;
+            const int a6 = rest % 6, r2 = rest / 6;
+            const int r = r2 % G::RG, qb = r2 / G::RG;          // qb = buffer * 2 + quad
+            sW[(qb >> 1) * G::WB + w6_slot<GEO>(qb & 1, r, a6, 15 + c3)] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     W6_STAMP();                                       // 0: start
     // ---- prologue ----------------------------------------------------------------------------------------------------------------
     // the halos of chunks 0 and 1 and the first weights are requested together: one memory round trip before the first MFMA
@@ -299,8 +338,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     auto rd = [&](const f32x4* wrow, bool second, int h) {
         const f32x2* w2 = reinterpret_cast<const f32x2*>(wrow) + h;
         X5 x;
-        if (!second) { x.x0 = w2[0 * 2]; x.x1 = w2[12 * 2]; x.x2 = w2[24 * 2]; x.x3 = w2[36 * 2]; x.x4 = w2[1 * 2]; }
-        else         { x.x0 = w2[12 * 2]; x.x1 = w2[24 * 2]; x.x2 = w2[36 * 2]; x.x3 = w2[1 * 2]; x.x4 = w2[13 * 2]; }
+        constexpr int K = G::CK;
+        if (!second) { x.x0 = w2[0 * 2]; x.x1 = w2[K * 2]; x.x2 = w2[2 * K * 2]; x.x3 = w2[3 * K * 2]; x.x4 = w2[1 * 2]; }
+        else         { x.x0 = w2[K * 2]; x.x1 = w2[2 * K * 2]; x.x2 = w2[3 * K * 2]; x.x3 = w2[1 * 2]; x.x4 = w2[(K + 1) * 2]; }
         return x;
     };
     auto rdB = [&](const f32x4* wrow, int h) {       // row B: which half is wave-uniform; kept a branch (the empty asm) so that only one runs
@@ -462,10 +502,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
             }
             // this entry is accumulator register 4*wave + 2q + rr of lane half hh: tile m
             const int m = 2 * q + rr + 8 * wave + 4 * hh;
-            const int mt = (m * 205) >> 11, mtc = m - mt * W6_TC;         // m / 10 for m < 32
+            int mimg, mt, mtc;
+            G::tile_of(m, mimg, mt, mtc);
             const int oh = oh0 + 4 * mt, ow = ow0 + 4 * mtc;
-            const bool tile_ok = cvalid && m < W6_TR * W6_TC;
-            float* yp0 = yimg + ((long)oh * W + ow) * a.y_cs;
+            const bool tile_ok = cvalid && m < G::TILES && n + mimg < P.N;
+            float* yp0 = yimg + (((long)mimg * H + oh) * W + ow) * a.y_cs;
             float yv[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -525,12 +566,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     }
 }
 
-int launch_wino6(ConvArgs& a, hipStream_t st) {
+template <int GEO>
+static int launch_wino6_geo(ConvArgs& a, hipStream_t st) {
     static DeviceOnce once;
     int rc = once.run([]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W6_LDS_ALLOC);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<false, GEO>), hipFuncAttributeMaxDynamicSharedMemorySize, w6_lds_alloc<GEO>());
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W6_LDS_ALLOC);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino6_kernel<true, GEO>), hipFuncAttributeMaxDynamicSharedMemorySize, w6_lds_alloc<GEO>());
         return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_wino6: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     });
     if (rc) return rc;
@@ -538,9 +580,14 @@ int launch_wino6(ConvArgs& a, hipStream_t st) {
     for (int i = 0; i < a.nprob; ++i) {
         ConvProblem& p = a.p[i];
         p.tile_begin = blocks;
-        p.tiles_h = cdiv(p.Ho, W6_OH);
-        p.tiles_w = cdiv(p.Wo, W6_OW);
-        blocks += p.N * p.tiles_h * p.tiles_w;
+        if (GEO == 0) {
+            p.tiles_h = cdiv(p.Ho, W6G<0>::OH);
+            p.tiles_w = cdiv(p.Wo, W6G<0>::OW);
+            blocks += p.N * p.tiles_h * p.tiles_w;
+        } else {
+            p.tiles_h = p.tiles_w = 1;
+            blocks += cdiv(p.N, 2);
+        }
     }
     a.grid_y = cdiv(a.Cout, 32);
     a.total_tiles = blocks;
@@ -553,10 +600,18 @@ int launch_wino6(ConvArgs& a, hipStream_t st) {
 #endif
     const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y);
     if (a.p[0].in_scale)
-        hipLaunchKernelGGL(conv_wino6_kernel<true>, grid, dim3(256), W6_LDS_ALLOC, st, a);
+        hipLaunchKernelGGL((conv_wino6_kernel<true, GEO>), grid, dim3(256), w6_lds_alloc<GEO>(), st, a);
     else
-        hipLaunchKernelGGL(conv_wino6_kernel<false>, grid, dim3(256), W6_LDS_ALLOC, st, a);
+        hipLaunchKernelGGL((conv_wino6_kernel<false, GEO>), grid, dim3(256), w6_lds_alloc<GEO>(), st, a);
     return check_launch("conv_wino6");
+}
+
+// geo 0: 12x40-pixel tiles of one image; geo 1: pairs of whole maps of at most 16 rows x 14 columns (one problem, no fused GN statistics)
+int launch_wino6(ConvArgs& a, int geo, hipStream_t st) {
+    if (geo == 0) return launch_wino6_geo<0>(a, st);
+    if (a.nprob != 1 || a.p[0].H > 16 || a.p[0].W > 14 || a.gn_ws)
+        return fail(CMK_EINVAL, "conv_wino6: the RoI-pair geometry takes one problem of maps up to 16x14 and produces no GroupNorm statistics%s", "");
+    return launch_wino6_geo<1>(a, st);
 }
 
 }  // namespace cmk

@@ -290,7 +290,7 @@ def _tune(descs, n, key) -> None:
         cands += [(7, 32, wn, sk) for wn in (1, 2, 4) for sk in sks]      # gather form
     if ALLOW_WINOGRAD:
         cands += [(5, 16, 2, 1)]                  # fused Winograd F(2x2,3x3)
-        cands += [(6, 16, 1, 1)]                  # fused Winograd F(4x4,3x3) (rejected by the library where it does not apply)
+        cands += [(6, 16, 1, 1), (6, 16, 2, 1)]   # fused Winograd F(4x4,3x3): map tiles / pairs of RoI maps (the library rejects what does not apply)
     for tv in cands:
         ws = _set_variant(descs, n, tv)
         if run() != 0:
@@ -732,8 +732,9 @@ def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) 
     wm, sc, wn = (tuple(tv[:3]) if tv else (0, 0, 0))
     if wm == 5:      # workgroup = 8x16 outputs x 64 couts: 256 MFMAs of 4096 FLOP per 16-channel chunk
         return float(sum(n * cd(h, 8) * cd(w, 16) for n, h, w in shapes) * cd(cout, 64) * (cin_pad // 16) * 256 * 4096)
-    if wm == 6:      # workgroup = 12x40 outputs x 32 couts: 144 MFMAs per 8-channel chunk
-        return float(sum(n * cd(h, 12) * cd(w, 40) for n, h, w in shapes) * cd(cout, 32) * (cin_pad // 8) * 144 * 4096)
+    if wm == 6:      # workgroup = 12x40 outputs (wn 1) or two whole RoI maps (wn 2) x 32 couts: 144 MFMAs per 8-channel chunk
+        wgs = sum(cd(n, 2) for n, h, w in shapes) if wn == 2 else sum(n * cd(h, 12) * cd(w, 40) for n, h, w in shapes)
+        return float(wgs * cd(cout, 32) * (cin_pad // 8) * 144 * 4096)
     cout_pad = _lib.load().cmk_conv_cout_pad(cout)
     if wm not in (1, 2):                      # cost-model / gather / split-K variants: geometry of the smallest tile
         wm, sc = 1, (32 if taps == 1 else 16)
@@ -754,7 +755,7 @@ def _kernel_name(taps, stride, tv, aff=False) -> str:
     if tv[0] == 5:
         return "conv_wino4r_kernel<{}>".format("true" if aff else "false")
     if tv[0] == 6:
-        return "conv_wino6_kernel<{}>".format("true" if aff else "false")
+        return "conv_wino6_kernel<{}, {}>".format("true" if aff else "false", 1 if tv[2] == 2 else 0)
     wm, sc, wn = tv[:3]
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)

@@ -78,7 +78,8 @@ typedef struct {
      * With tune_wm == 6 the records are per (spatial tile of 12x40 outputs, wave 0..3, group): index ((tile*4 + wave)*gn_groups + group);
      * cmk_conv_gn_records(H, W, tune_wm) gives the records per image of either form. */
     double* gn_ws; int gn_groups;
-    /* tune_wm == 6 selects the fused Winograd F(4x4,3x3) kernel (conv_wino6.hip; 3x3 stride 1, no residual, Cin % 8 == 0): 36 multiplies
+    /* tune_wm == 6 selects the fused Winograd F(4x4,3x3) kernel (conv_wino6.hip; 3x3 stride 1, no residual, Cin % 8 == 0; tune_wn 1 = 12x40-pixel
+     * tiles of one image, tune_wn 2 = two whole maps of at most 16 rows x 14 columns per workgroup, for the 14x14 RoI features): 36 multiplies
      * per 4x4 outputs, 1.78x fewer than F(2x2,3x3); fp32 throughout, error ~1.6x the 2x2 form's (tools/wino_numerics.py).  Needs
      * U = G g G^T (6x6 per filter, points 0, +-1, +-2, inf), cmk_wino6_packed_floats floats packed
      * [Cin/8][ceil(Cout/32)][wave 4][slot 9][lane 64][4 floats]: slot k < 6 is frequency (row = wave, column = k), slot k >= 6 is

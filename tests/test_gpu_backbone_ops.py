@@ -244,6 +244,24 @@ def test_conv_winograd6_variant(dev, case):
     assert rc == 0
 
 
+@pytest.mark.parametrize("case", [(6, 14, 14, 256, 80), (5, 14, 14, 272, 256), (3, 16, 14, 32, 64), (2, 7, 7, 64, 32), (1, 14, 14, 64, 33)])
+def test_conv_winograd6_roi_pair_geometry(dev, case):
+    """tune_wm 6 / tune_wn 2: two whole RoI maps (at most 16 rows x 14 columns) per workgroup — even and odd batch, the 272-channel
+    mask-IoU input, maps smaller than 14x14, Cout not a multiple of 32."""
+    n, h, w, cin, cout = case
+    x = _rand((n, cin, h, w), 91)
+    wt = _rand((cout, cin, 3, 3), 92, (2.0 / (cin * 9)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(93)) + 0.5
+    shift = _rand((cout,), 94, 0.1)
+    ref = F.relu(F.conv2d(x, wt, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    rc, y = _run_variant(dev, x, wt, scale, shift, (6, 16, 2))
+    assert rc == 0
+    _close(y.nchw(), ref)
+    # maps wider than 14 columns are refused by this geometry
+    rc, _ = _run_variant(dev, _rand((2, 32, 14, 15), 95), _rand((32, 32, 3, 3), 96, 0.05), None, None, (6, 16, 2))
+    assert rc != 0
+
+
 def test_conv_winograd6_channel_views(dev):
     """tune_wm 6 reading a channel slice of a wider buffer (an OSA concat buffer) and writing into a slice of another; partial ReLU."""
     import ctypes
