@@ -361,6 +361,8 @@ def install(reference_root="/root/reference"):
     _mod("detectron2.data")
     _mod("detectron2.data.datasets")
     _mod("detectron2.data.datasets.coco")
+    _mod("detectron2.data.transforms")            # deploy_utils.py imports these names; the tuple helpers it is imported for use none of them
+    _mod("detectron2.export")
     _mod("fvcore")
     fnn = _mod("fvcore.nn")
     wi = _mod("fvcore.nn.weight_init")

@@ -129,6 +129,23 @@ def test_shipped_variant_tables_name_existing_kernels(tmp_path):
         ops._TUNED.update(saved)
 
 
+def test_bin_sextuple_fixture_from_the_reference(tmp_path):
+    """tests/golden/bin/000000000139_{1..6}.bin: written from the tuple of the reference's own single_flatten_to_tuple and read back by
+    its own reader steps (tests/golden/make_golden_bin.py).  wire.from_bin must parse them to the same tensors, wire.to_bin must write
+    the same bytes."""
+    from centermask2_amd import wire
+    from .helpers import GOLDEN, golden
+    exp = golden("bin_expected")
+    prefix = os.path.join(GOLDEN, "bin", "000000000139")
+    got = wire.from_bin(prefix)
+    names = ("locations", "mask_scores", "pred_boxes", "pred_classes", "pred_masks", "scores")
+    for k, t in zip(names, got):
+        assert t.dtype == exp[k].dtype and torch.equal(t, exp[k]), k
+    paths = wire.to_bin(tuple(exp[k] for k in names), str(tmp_path / "000000000139"))
+    for i, pth in enumerate(paths):
+        assert open(pth, "rb").read() == open("{}_{}.bin".format(prefix, i + 1), "rb").read(), pth
+
+
 def test_structures():
     from centermask2_amd.structures import Boxes, FakeImageList, ImageList, Instances
     b = Boxes(torch.tensor([[0., 0., 10., 20.], [5., 5., 5., 9.]]))

@@ -48,3 +48,23 @@ def test_detector_postprocess_and_mask_paste(dev):
     mismatch = (got != want).float().mean().item()
     assert mismatch < 1e-5, mismatch          # pixels whose interpolated value sits within rounding of the 0.5 threshold
     assert postprocess.resize_scale(427, 640) == pytest.approx(800 / 427)
+
+
+def test_wire_bin_sextuple_from_the_hip_path(dev, tmp_path):
+    """SURVEY 8(f)3 on the GPU path: the model's 6-tuple (modified_class.py:28-40 order) written as the deployment flow's six .bin files,
+    against the files the REFERENCE's own modules and tuple helper produced for the same image (tests/golden/bin, make_golden_bin.py)."""
+    import os
+    from centermask2_amd import synthetic as S, wire
+    from .helpers import GOLDEN, build_gpu_model, close, golden
+    exp = golden("bin_expected")
+    model, _ = build_gpu_model()
+    x = S.make_synthetic_images(1, 256, 320, seed0=4321).to(dev)
+    t6 = model.forward_tensor(x, hw=[(256, 320)])
+    torch.cuda.synchronize()
+    paths = wire.to_bin(tuple(t[:5] for t in t6), str(tmp_path / "000000000139"))
+    assert [os.path.getsize(p) for p in paths] == [os.path.getsize(os.path.join(GOLDEN, "bin", "000000000139_{}.bin".format(i + 1))) for i in range(6)]
+    got = wire.from_bin(str(tmp_path / "000000000139"))
+    names = ("locations", "mask_scores", "pred_boxes", "pred_classes", "pred_masks", "scores")
+    assert torch.equal(got[0], exp["locations"]) and torch.equal(got[3], exp["pred_classes"]) and got[3].dtype == torch.int64
+    for i, tol in ((1, 1e-3), (2, 2e-5), (4, 1e-3), (5, 1e-4)):
+        close(got[i], exp[names[i]], tol, names[i])
