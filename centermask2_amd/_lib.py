@@ -75,6 +75,7 @@ SIGNATURES = {
     "cmk_mask_pool_concat": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_preprocess_chw": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "cmk_paste_masks": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "cmk_pack_records": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cmk_mask_iou_score": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
 }
 

@@ -50,9 +50,40 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
     out[((long)r * H + y) * W + x] = (v >= thr) ? 1 : 0;
 }
 
+// Fixed-stride per-image result record for the multi-GPU all-gather: one pass over the padded result buffers,
+// straight into the send buffer:  [box 4K | score K | mask_score K | loc 2K | cls K (as float) | mask K*S*S | count].  grid = (blocks, N)
+__global__ __launch_bounds__(256) void pack_records_kernel(const float* __restrict__ box, const float* __restrict__ score, const float* __restrict__ mscore,
+                                                          const float* __restrict__ loc, const int64_t* __restrict__ cls, const float* __restrict__ masks,
+                                                          const int32_t* __restrict__ counts, int K, int SS, float* __restrict__ rec, int width) {
+    const int n = blockIdx.y;
+    float* r = rec + (long)n * width;
+    const int o_score = 4 * K, o_ms = 5 * K, o_loc = 6 * K, o_cls = 8 * K, o_mask = 9 * K, o_cnt = 9 * K + K * SS;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < width; i += gridDim.x * 256) {
+        float v;
+        if (i < o_score) v = box[(long)n * 4 * K + i];
+        else if (i < o_ms) v = score[(long)n * K + (i - o_score)];
+        else if (i < o_loc) v = mscore[(long)n * K + (i - o_ms)];
+        else if (i < o_cls) v = loc[(long)n * 2 * K + (i - o_loc)];
+        else if (i < o_mask) v = (float)cls[(long)n * K + (i - o_cls)];
+        else if (i < o_cnt) v = masks[(long)n * K * SS + (i - o_mask)];
+        else v = (float)counts[n];
+        r[i] = v;
+    }
+}
+
 }  // namespace cmk
 
 using namespace cmk;
+
+extern "C" int cmk_pack_records(const float* box, const float* score, const float* mask_scores, const float* loc, const int64_t* cls,
+                                const float* masks, const int32_t* counts, int N, int K, int mask_hw, float* rec, void* stream) {
+    if (!box || !score || !mask_scores || !loc || !cls || !masks || !counts || !rec) return fail(CMK_EINVAL, "pack_records: null pointer%s", "");
+    if (N < 1 || K < 1 || mask_hw < 1) return fail(CMK_EINVAL, "pack_records: bad shape%s", "");
+    const int width = K * (9 + mask_hw * mask_hw) + 1;
+    hipLaunchKernelGGL(pack_records_kernel, dim3(cdiv(width, 256 * 4), N), dim3(256), 0, (hipStream_t)stream, box, score, mask_scores, loc, cls, masks,
+                       counts, K, mask_hw * mask_hw, rec, width);
+    return check_launch("pack_records");
+}
 
 extern "C" int cmk_preprocess_chw(const void* src, int src_is_u8, float* dst, int h, int w, int H, int W, const float* mean3,
                                   const float* std3, void* stream) {

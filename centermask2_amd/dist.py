@@ -24,12 +24,25 @@ def record_width(topk: int, mask_hw: int = 28) -> int:
     return topk * (4 + 1 + 1 + 2 + 1 + mask_hw * mask_hw) + 1
 
 
-def pack_records(out: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """(n, record_width) float32: [box 4K | score K | mask_score K | loc 2K | cls K | mask 784K | count]."""
-    n = out["score"].shape[0]
-    return torch.cat([out["box"].reshape(n, -1), out["score"], out["mask_scores"], out["loc"].reshape(n, -1),
-                      out["cls"].to(torch.float32), out["pred_masks"].reshape(n, -1),
-                      out["counts"].to(torch.float32).reshape(n, 1)], dim=1).contiguous()
+def pack_records(out: Dict[str, torch.Tensor], rec: torch.Tensor = None) -> torch.Tensor:
+    """(n, record_width) float32: [box 4K | score K | mask_score K | loc 2K | cls K | mask 784K | count].
+    On the GPU this is ONE kernel (cmk_pack_records) writing straight into `rec` — pass the all-gather send buffer to reuse it every
+    step; on CPU tensors (the gloo tests of the exchange logic) the same layout is assembled with torch ops."""
+    n, k = out["score"].shape
+    hw = out["pred_masks"].shape[-1]
+    if not out["score"].is_cuda:
+        return torch.cat([out["box"].reshape(n, -1), out["score"], out["mask_scores"], out["loc"].reshape(n, -1),
+                          out["cls"].to(torch.float32), out["pred_masks"].reshape(n, -1),
+                          out["counts"].to(torch.float32).reshape(n, 1)], dim=1).contiguous()
+    from . import _lib, ops
+    if rec is None:
+        rec = torch.empty((n, record_width(k, hw)), dtype=torch.float32, device=out["score"].device)
+    assert rec.shape == (n, record_width(k, hw)) and rec.is_contiguous()
+    ops._need_gpu(out["score"], "pack_records")
+    _lib.check(_lib.load().cmk_pack_records(out["box"].data_ptr(), out["score"].data_ptr(), out["mask_scores"].data_ptr(), out["loc"].data_ptr(),
+                                            out["cls"].data_ptr(), out["pred_masks"].data_ptr(), out["counts"].data_ptr(), n, k, hw,
+                                            rec.data_ptr(), ops._stream()), "cmk_pack_records")
+    return rec
 
 
 def unpack_records(rec: torch.Tensor, topk: int, mask_hw: int = 28) -> Dict[str, torch.Tensor]:

@@ -214,6 +214,12 @@ int cmk_preprocess_chw(const void* src, int src_is_u8, float* dst, int h, int w,
 int cmk_paste_masks(const float* masks, const float* boxes, int R, int S, int H, int W, float threshold, uint8_t* out,
                     void* stream);
 
+/* ---- multi-GPU result exchange (the reference's analogue: comm.gather in evaluation/coco_evaluation.py:155-156) ----------
+ * One fixed-stride float record per image, written straight into the all-gather send buffer:
+ * [box 4K | score K | mask_score K | loc 2K | class K (as float) | mask K*hw*hw | count], K*(9 + hw*hw) + 1 floats. */
+int cmk_pack_records(const float* box, const float* score, const float* mask_scores, const float* loc, const int64_t* cls,
+                     const float* masks, const int32_t* counts, int N, int K, int mask_hw, float* rec /* N * width */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

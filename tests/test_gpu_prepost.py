@@ -68,3 +68,19 @@ def test_wire_bin_sextuple_from_the_hip_path(dev, tmp_path):
     assert torch.equal(got[0], exp["locations"]) and torch.equal(got[3], exp["pred_classes"]) and got[3].dtype == torch.int64
     for i, tol in ((1, 1e-3), (2, 2e-5), (4, 1e-3), (5, 1e-4)):
         close(got[i], exp[names[i]], tol, names[i])
+
+
+def test_pack_records_kernel_matches_layout(dev):
+    """cmk_pack_records (the all-gather send record, one launch) against the torch assembly of the same layout, and the round trip."""
+    from centermask2_amd.dist import pack_records, record_width, unpack_records
+    g = torch.Generator().manual_seed(9)
+    n, k = 3, 50
+    out = dict(box=torch.rand((n, k, 4), generator=g) * 900, score=torch.rand((n, k), generator=g), mask_scores=torch.rand((n, k), generator=g),
+               loc=torch.rand((n, k, 2), generator=g) * 1280, cls=torch.randint(0, 80, (n, k), generator=g), pred_masks=torch.rand((n, k, 1, 28, 28), generator=g),
+               counts=torch.tensor([50, 0, 17], dtype=torch.int32))
+    want = pack_records(out)                                      # CPU tensors: torch assembly
+    got = pack_records({kk: v.to(dev) for kk, v in out.items()})  # GPU tensors: the kernel
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (n, record_width(k)) and torch.equal(got.cpu(), want)
+    back = unpack_records(got.cpu(), k)
+    assert torch.equal(back["cls"], out["cls"]) and torch.equal(back["counts"], out["counts"]) and torch.equal(back["pred_masks"], out["pred_masks"])
