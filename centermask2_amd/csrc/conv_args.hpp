@@ -36,7 +36,6 @@ struct ConvArgs {
     double* gn_ws;     // Winograd 2-WG form: per (spatial tile, row parity, group) partial {sum, sum of squares} of the outputs (fused GroupNorm statistics)
     int gn_cpg, gn_groups;
     int ga_stride;     // gather form (GA): stride of the 3x3 conv whose taps are walked as 9x more K chunks
-    int stagger_sleeps;   // conv_wino6 (W6_STAGGER builds): s_sleep 127 periods the second resident workgroup of a CU waits at launch
     int grid_y;   // N tiles; the N-tile index is the FASTEST block coordinate so the workgroups sharing an input tile run together (L2 reuse)
 };
 

@@ -148,6 +148,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
 
     // XCD-aware order, as in the other conv kernels: the grid_y cout tiles of one spatial tile go to the same XCD, back to back
     const int xq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    // (the opposite, weight-stationary mapping — XCD k takes the cout tiles == k mod 8 of every spatial tile so that its L2 holds 1/8 of
+    // U — was measured 3-4 % slower on the 256 -> 256 layers: every XCD then reads the whole input)
     const int bx = (xq / a.grid_y) * 8 + xcd, by = xq % a.grid_y;
     if (bx >= a.total_tiles) return;
     int pi = 0;
@@ -275,19 +277,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     }
 #else
 #define W6_STAMP() do { } while (0)
-#endif
-#ifdef W6_STAGGER
-    // Two workgroups share a CU and, launched together with equal work, stay in lock-step for the whole launch: both in their prologue,
-    // both in their loop, both in their epilogue — nothing covers the ~25 % of a workgroup's life in which it feeds the matrix pipe
-    // nothing (tools/ab/trace_wino6.py).  Delay the second one ONCE, at launch, by about half a workgroup life; every later workgroup
-    // starts when its predecessor on the same slot ends and inherits the phase.  Which of the two a wave belongs to: the wave slot
-    // it got in its SIMD (HW_ID.WAVE_ID, bits 3:0) — the first resident workgroup holds slot 0, the second slot 1.  Nothing depends on
-    // this for correctness.
-    if (blockIdx.x < 512 && a.stagger_sleeps > 0) {
-        const unsigned hw_id = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));      // HW_REG_HW_ID, offset 0, 4 bits
-        if (hw_id & 1u)
-            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);            // ~8100 cycles each
-    }
 #endif
     if (GEO == 1) {
         // halo columns 15..17 (image columns >= 14) are zero for every image this geometry accepts: their W slots are cleared here, once,
@@ -591,13 +580,6 @@ static int launch_wino6_geo(ConvArgs& a, hipStream_t st) {
     }
     a.grid_y = cdiv(a.Cout, 32);
     a.total_tiles = blocks;
-#ifdef W6_STAGGER
-    {   // half a workgroup life in units of s_sleep 127 (~4.2 us): life ~ 14 us + 3.3 us per 8-channel chunk; only where the launch
-        // is long enough (>= 4 rounds of 512 workgroups) for the one-off delay to pay
-        const long wgs = (long)blocks * a.grid_y;
-        a.stagger_sleeps = wgs >= 4 * 512 ? (int)((14.0 + 3.3 * (a.Cin >> 3)) / 2.0 / 4.2 + 0.5) : 0;
-    }
-#endif
     const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y);
     if (a.p[0].in_scale)
         hipLaunchKernelGGL((conv_wino6_kernel<true, GEO>), grid, dim3(256), w6_lds_alloc<GEO>(), st, a);

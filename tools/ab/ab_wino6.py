@@ -3,7 +3,7 @@ One subprocess per (round, library), interleaved, best-of per shape — box-to-b
 import sys, os, subprocess
 SHAPES = [("stem_2", 400, 640, 64, 64), ("OSA2_x", 200, 320, 128, 128), ("OSA3_0", 100, 160, 256, 160), ("OSA3_x", 100, 160, 160, 160),
           ("OSA4_0", 50, 80, 512, 192), ("OSA4_x", 50, 80, 192, 192), ("OSA5_x", 25, 40, 224, 224), ("fpn_p3", 100, 160, 256, 256),
-          ("fcos_p4", 50, 80, 256, 256)]
+          ("fcos_p4", 50, 80, 256, 256), ("OSA5_0", 25, 40, 768, 224), ("roi", 14, 14, 256, 256)]
 if sys.argv[1] != "--one":
     args = sys.argv[1:]
     rounds, wm = 3, "6"
@@ -33,11 +33,11 @@ from centermask2_amd.ops import View
 lib = _lib.load(); dev = torch.device("cuda:0"); out = []
 wm = int(sys.argv[3])
 for name, h, w, cin, cout in SHAPES:
-    n = 8
+    n = 400 if name == "roi" else 8
     x = View(torch.randn((n, h, w, cin), device=dev)); pc = ops.PackedConv(torch.randn((cout, cin, 3, 3)) * 0.05, None, None, dev)
     y = View(torch.empty((n, h, w, cout), device=dev))
     d = (_lib.ConvDesc * 1)(); ops._fill_desc(d[0], x, pc, y, True, None, None, False, False)
-    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = wm, 16, (1 if wm == 6 else 2)
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = wm, 16, ((2 if name == "roi" else 1) if wm == 6 else 2)
     for _ in range(10): assert lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
