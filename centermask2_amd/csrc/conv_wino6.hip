@@ -239,12 +239,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     };
 
     // ---- MFMA side -------------------------------------------------------------------------------------------------------------
-    // A operand row li = tile m = 10*t + tc (m = 30, 31: no tile; they read initialised-or-not LDS, their accumulator rows are never
-    // stored); lane half hh = channel quad; accumulator register r of lane half hh is tile m = (r & 3) + 8*(r >> 2) + 4*hh, column
+    // A operand row li = tile m (GEO 0: m = 10*t + tc, rows 30, 31 carry no tile and their accumulator rows are never stored); lane half hh = channel quad; accumulator register r of lane half hh is tile m = (r & 3) + 8*(r >> 2) + 4*hh, column
     // li = output channel co0 + li
     const int rowA = wave, rowB = 4 + (wave >> 1), halfB = wave & 1;
     int m_img, m_t, m_tc;
-    G::tile_of(li, m_img, m_t, m_tc);
+    G::tile_of(min(li, G::TILES - 1), m_img, m_t, m_tc);     // GEO 0: rows 30, 31 carry no tile; they re-read tile 29's samples (never stored)
     const f32x4* wl = sW + w6_slot<GEO>(hh, (GEO == 1 ? 4 * m_img : 0) + m_t, 0, 4 * m_tc);
     const f32x4* wA = wl + rowA * W6_AP;
     const f32x4* wB = wl + rowB * W6_AP;
@@ -377,12 +376,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
 #define W6_STAMP_AT(slot) do { } while (0)
 #endif
         W6_STAMP_AT(50);
+        // AHEAD (variants without the fused input affine): the LDS reads of half-step k+1 are issued in front of the MFMAs of half-step k.
+        // With the affine its scale/shift registers leave no room for the second sample set (6 spilled registers, reloaded every period):
+        // there each half-step reads its own samples.
+        constexpr bool AHEAD = !AFF;
         load_U(min(step + 2, total_steps - 1), 2);
-        X5 xa = rd(wA + wcur, false, 0);
-        X5 xb = rd(wA + wcur, false, 1);
+        X5 xa = rd(wA + wcur, false, 0), xb;
+        if (AHEAD) xb = rd(wA + wcur, false, 1);
         half_step(xa, false, 0, 0, 0);
         W6_STAMP_AT(51);                              // after reads + transform + 6 MFMAs issued
-        xa = rd(wA + wcur, true, 0);
+        if (AHEAD) xa = rd(wA + wcur, true, 0); else xb = rd(wA + wcur, false, 1);
         half_step(xb, false, 1, 0, 0);
         W6_STAMP_AT(52);                              // step 0 issued
         W6_FENCE;
@@ -396,15 +399,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
         W6_STAMP_AT(54);                              // halo loads issued
         W6_FENCE;
         load_U(min(step + 3, total_steps - 1), 0);
-        xb = rd(wA + wcur, true, 1);
+        if (AHEAD) xb = rd(wA + wcur, true, 1); else xa = rd(wA + wcur, true, 0);
         half_step(xa, true, 0, 1, 3);
-        xa = rdB(wB + wcur, 0);
+        if (AHEAD) xa = rdB(wB + wcur, 0); else xb = rd(wA + wcur, true, 1);
         half_step(xb, true, 1, 1, 3);
         W6_STAMP_AT(55);                              // step 1 issued
         W6_FENCE;
         load_U(min(step + 4, total_steps - 1), 1);
-        xb = rdB(wB + wcur, 1);
+        if (AHEAD) xb = rdB(wB + wcur, 1); else xa = rdB(wB + wcur, 0);
         half_stepB(xa, 0);
+        if (!AHEAD) xb = rdB(wB + wcur, 1);
         half_stepB(xb, 1);
         W6_STAMP_AT(56);                              // step 2 issued
     }
