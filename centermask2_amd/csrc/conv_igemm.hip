@@ -934,6 +934,12 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     }
     a.ksplit = d->splitk > 1 ? d->splitk : 1;
     a.ws = d->splitk_ws;
+    if (d->tune_wm == 8) {                             // pointwise GEMM kernel (conv_pw.hip); tune_wn = accumulator rows per wave
+        if (d->ksize != 1 || cout32 <= 7) return fail(CMK_EINVAL, "conv: pointwise variant needs a 1x1 conv with Cout > 224%s", "");
+        a.cout_pad = cdiv(cout32, 4) * 128;
+        a.gn_ws = d->gn_ws;
+        return launch_pw(a, d->tune_wn, st);
+    }
     if (d->tune_wm == 7) {                             // gather form: 3x3 (stride 1|2) as a flattened-pixel GEMM over 9x the K chunks
         if (d->ksize != 3 || n != 1 || d->res_mode == 2 || d->in_scale || (d->tune_wn != 1 && d->tune_wn != 2 && d->tune_wn != 4))
             return fail(CMK_EINVAL, "conv: gather variant not available for this conv%s", "");
@@ -996,6 +1002,17 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
             const int gy = cout_pad32 / wn;
             return wn == 4 ? launch<1, 1, 1, 4, 32, true>(a, gy, st) : wn == 2 ? launch<1, 1, 1, 2, 32, true>(a, gy, st)
                                                                                : launch<1, 1, 1, 1, 32, true>(a, gy, st);
+        }
+        // 1x1 convs with enough pixels and output channels to fill the chip: the pointwise GEMM kernel (conv_pw.hip; measured 1.12-1.2x
+        // conv_igemm on every concat / lateral / deconv shape of the model, tools/bench_pw.py), 256-pixel workgroups from 2 rounds on
+        if (d->ksize == 1 && n == 1 && cout32 > 7 && !(d->Cin & 31) && !d->in_scale && !d->in_relu && d->res_mode != 2 && a.ksplit == 1 &&
+            a.p[0].total_pix * d->x_cs * 4 < (1L << 31)) {
+            const long ctiles = cdiv(cout32, 4);
+            const long wg2 = ((a.p[0].total_pix + 127) / 128) * ctiles, wg4 = ((a.p[0].total_pix + 255) / 256) * ctiles;
+            if (wg2 >= 256) {
+                a.cout_pad = (int)ctiles * 128;
+                return launch_pw(a, wg4 >= 1024 ? 4 : 2, st);
+            }
         }
         v = choose_variant(a, taps, d->stride, cout32);
     }

@@ -1,0 +1,327 @@
+// Pointwise (1x1) convolution of the big aggregation layers as a plain fp32 GEMM on the matrix pipe, built the way the F(4x4) kernel
+// taught (conv_wino6.hip): what limits these kernels on MI355X is the energy spent moving operands, not issue slots.
+//
+//   GEMM view: M = flattened pixels (N*H*W), N = output channels, K = Cin; v_mfma_f32_32x32x2_f32, pixels on the accumulator rows,
+//   output channels on the lanes (128-byte NHWC stores).
+//   Workgroup = 4 waves as 2 (pixels) x 2 (couts); wave tile = MT x 2 accumulators of 32 px x 32 couts (MT = 4: 128 px x 64 couts,
+//   workgroup 256 px x 128 couts; MT = 2 for layers with too few pixels to fill the chip with the large tile); two workgroups per CU.
+//   Operand traffic per MFMA: 1 activation register from LDS per 2 MFMAs (each ds_read_b128 feeds 4 k-steps x 2 cout tiles), one
+//   weight register per MT MFMAs straight from L2/L1 into registers (no LDS slab, no barrier dependence, fetched two chunks ahead through
+//   a wave-uniform scalar base) — 0.75 operand registers per MFMA where the 32 px x 128 couts wave tile of conv_igemm took 1.25, and half
+//   its global->LDS staging bytes.  The activations are staged global -> registers -> LDS once per workgroup and 16-channel chunk with
+//   raw buffer loads (rows past the last pixel come back as zeros from the hardware range check: no selects), double-buffered, one
+//   barrier per chunk = per 64 (MT = 4) MFMAs of a wave.
+//   The weights are the layout conv_igemm already packs ([chunk][cout_pad][16 channels]); K order and accumulation order are the
+//   same as conv_igemm's, so the two kernels agree bit for bit.
+//
+// Reference call sites replaced: the OSA concat 1x1 convs (vovnet.py:222-236), FPN laterals, the mask head's deconv as a 1x1.
+#include <math.h>
+
+#include <type_traits>
+
+#include "conv_args.hpp"
+
+namespace cmk {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 pw_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
+    constexpr int BM = 64 * MT;         // pixels per workgroup
+    constexpr int ABUF = BM * PST;      // floats per LDS buffer (rows of 16 channels, pitch 20)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, li = lane & 31;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // XCD-aware order: the cout tiles of one pixel tile run back to back on one XCD (they share the activations in its L2)
+    const int xq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int bx = (xq / a.grid_y) * 8 + xcd, by = xq % a.grid_y;
+    if (bx >= a.total_tiles) return;
+    const ConvProblem& P = a.p[0];
+    const long total_pix = P.total_pix;
+    const long pix0 = (long)bx * BM;
+    const int co0 = by * 128 + wn * 64;
+    const int nchunks = a.Cin >> 4;     // even (host)
+
+    // ---- activations: global -> registers -> LDS ------------------------------------------------------------------------------------
+    // thread = (row tid>>2 (+64 per iteration), channel quad tid&3); a row past the last pixel gets an offset outside the resource
+    i32x4 rsrc;
+    {
+        const unsigned long long base = (unsigned long long)P.x;
+        rsrc.x = __builtin_amdgcn_readfirstlane((int)(base & 0xffffffffull));
+        rsrc.y = __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffull));
+        rsrc.z = __builtin_amdgcn_readfirstlane((int)(total_pix * a.x_cs * 4));      // < 2^31 (host)
+        rsrc.w = 0x00020000;
+    }
+    int a_voff[MT];
+#pragma unroll
+    for (int it = 0; it < MT; ++it) {
+        const long px = pix0 + it * 64 + (tid >> 2);
+        a_voff[it] = px < total_pix ? (int)((px * a.x_cs + a.x_co + (tid & 3) * 4) * 4) : (int)0x80000000;
+    }
+    const int a_dst = (tid >> 2) * PST + (tid & 3) * 4;
+    f32x4 a_st[MT];
+    auto load_A = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < MT; ++it) a_st[it] = pw_buffer_load(rsrc, a_voff[it], chunk * 64, 0);
+    };
+    auto store_A = [&](int buf) {
+        float* dst = smem + buf * ABUF + a_dst;
+#pragma unroll
+        for (int it = 0; it < MT; ++it) *reinterpret_cast<f32x4*>(dst + it * 64 * PST) = a_st[it];
+    };
+
+    // ---- weights: L2 -> registers; lane (li, hh) takes channels 8*hh .. 8*hh+7 of output channel (tile base + li) ---------------------
+    const float* wbase[2];
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) wbase[nn] = a.w + (long)min(co0 + nn * 32, a.cout_pad - 32) * 16;     // wave-uniform
+    const long w_chunk = (long)a.cout_pad * 16;
+    const unsigned w_lane = li * 16 + hh * 8;
+    f32x4 bq[2][2][2];                  // [register set][cout tile][k-steps 0..3 | 4..7]
+    auto load_B = [&](int chunk, int set) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+            const float* src = wbase[nn] + chunk * w_chunk;
+            bq[set][nn][0] = *reinterpret_cast<const f32x4*>(src + w_lane);
+            bq[set][nn][1] = *reinterpret_cast<const f32x4*>(src + (w_lane + 4));
+        }
+    };
+
+    // ---- MFMA side --------------------------------------------------------------------------------------------------------------------
+    int a_off[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_off[m] = ((wm * MT + m) * 32 + li) * PST + hh * 8;
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+    f32x4 avA[MT], avB[MT];             // operands of the first / second half (4 k-steps each) of a chunk
+    auto rd = [&](f32x4 (&v)[MT], int buf, int h) {
+        const float* A = smem + buf * ABUF + 4 * h;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) v[m] = *reinterpret_cast<const f32x4*>(A + a_off[m]);
+    };
+    // 4 k-steps: channels 4h..4h+3 (lane half 0) and 8+4h..8+4h+3 (lane half 1) of the chunk — conv_igemm's order
+    auto mh = [&](const f32x4 (&v)[MT], int set, int h) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[m][s], bq[set][nn][h][s], acc[m][nn], 0, 0, 0);
+    };
+
+#ifdef PW_TRACE
+    // instrumented build (tools/ab/trace_pw.py): lane 0 of every wave of every 16th workgroup stamps the shader clock into LDS (a global
+    // store inside the loop would make every barrier drain the loads in flight) and copies the stamps to a.ws at the end:
+    // [0] start, [1] prologue done, [2+2c] barrier of chunk c reached, [3+2c] passed (c < 28), [58] loop done, [59] stores issued,
+    // [60] XCC id, [61] HW id, [62]/[63] real time at the end/start
+    const bool tracing = a.ws && (blockIdx.x % 16) == 0 && lane == 0;
+    unsigned long long* trl = reinterpret_cast<unsigned long long*>(smem + 2 * ABUF) + wave * 64;
+    unsigned long long* trc = reinterpret_cast<unsigned long long*>(a.ws) + ((blockIdx.x / 16) * 4 + wave) * 64;
+#define PW_STAMP(slot) do { if (tracing) trl[slot] = __builtin_readcyclecounter(); } while (0)
+    if (tracing) {
+        trl[63] = __builtin_amdgcn_s_memrealtime();
+        trl[61] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));
+        trl[60] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((32 - 1) << 11));
+    }
+    PW_STAMP(0);
+#else
+#define PW_STAMP(slot) do { } while (0)
+#endif
+    // PW_ABL (timing ablations, results wrong): 1 no barrier, 2 no activation loads, 4 no weight loads, 8 no LDS writes
+#ifndef PW_ABL
+#define PW_ABL 0
+#endif
+#if PW_ABL & 1
+#define PW_SYNC
+#else
+#define PW_SYNC __syncthreads()
+#endif
+#if PW_ABL & 2
+#define PW_LOAD_A(c)
+#else
+#define PW_LOAD_A(c) load_A(c)
+#endif
+#if PW_ABL & 4
+#define PW_LOAD_B(c, s)
+#else
+#define PW_LOAD_B(c, s) load_B(c, s)
+#endif
+#if PW_ABL & 8
+#define PW_STORE_A(b)
+#else
+#define PW_STORE_A(b) store_A(b)
+#endif
+    // ---- pipeline ------------------------------------------------------------------------------------------------------------------
+    // chunk c, LDS buffer u = c & 1, weight set u:
+    //   read the second-half operands of chunk c; 32 MFMAs of the first half, among them: A(c+1) (in registers since chunk c-1) into
+    //   buffer u^1, request A(c+2)
+    //   barrier: buffer u^1 is complete, everybody has read all of buffer u
+    //   read the first-half operands of chunk c+1; 32 MFMAs of the second half; request B(c+2) into set u
+    // No MFMA waits for an LDS round trip (each read has 32 MFMAs to land), the activations have a whole chunk to arrive, the weights
+    // more.  Measured with the trace build: reading all of a chunk's operands behind its barrier cost a wave alone on its SIMD 700 of
+    // 4800 cycles per chunk.
+    // The fences pin the order of the prologue's requests: the compiler's wait counts at the loop head are the minimum over the prologue's
+    // and the loop's order, so a weight request scheduled late there makes every chunk wait for younger loads than it needs.
+    load_A(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_A(0);
+    load_A(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    PW_STAMP(1);
+    PW_SYNC;
+    rd(avA, 0, 0);
+    for (int c = 0; c < nchunks; c += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            rd(avB, u, 1);
+            mh(avA, u, 0);
+            PW_STORE_A(u ^ 1);
+            PW_LOAD_A(min(c + u + 2, nchunks - 1));
+            __builtin_amdgcn_sched_barrier(0);      // (the compiler otherwise moves the second half's MFMAs in front of the barrier)
+#ifdef PW_TRACE
+            if (c + u < 28) PW_STAMP(2 + 2 * (c + u));
+#endif
+            PW_SYNC;
+#ifdef PW_TRACE
+            if (c + u < 28) PW_STAMP(3 + 2 * (c + u));
+#endif
+            rd(avA, u ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mh(avB, u, 1);
+            PW_LOAD_B(min(c + u + 2, nchunks - 1), u);
+        }
+    }
+
+    PW_STAMP(58);
+    // ---- epilogue: scale/shift (+same-size residual) (+ReLU), NHWC stores ------------------------------------------------------------------------
+    // accumulator register r of lane half hh is pixel row (r & 3) + 8 * (r >> 2) + 4 * hh of the 32-pixel sub-tile; the lane is the cout
+    const long wpix0 = pix0 + wm * (MT * 32);
+    float* ybase = P.y + wpix0 * a.y_cs;                                   // wave-uniform; rows are added to the lane offset below
+    const float* rbase = a.res_mode == 1 ? a.res + wpix0 * a.res_cs : nullptr;
+    const bool interior = a.res_mode == 0 && pix0 + BM <= total_pix && co0 + 64 <= a.Cout;
+    auto epilogue = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+            const int co = co0 + nn * 32 + li;
+            const bool cvalid = INTERIOR || co < a.Cout;
+            float sc = cvalid ? P.scale[co] : 0.f;
+            float sh = cvalid ? P.shift[co] : 0.f;
+            const float lo = co < a.relu_upto ? 0.f : __builtin_nanf("");      // max(v, NaN) = v: lanes without the ReLU
+            // the values are waited for once, here; the compiler cannot see through the asm and so does not put a full wait in front
+            // of every store (conv_wino6.hip)
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(sc), "+v"(sh));
+            if constexpr (INTERIOR) {
+                // Every VALU instruction of a wave in its epilogue waits for a gap in the MFMA stream of the other workgroup on the SIMD
+                // (and takes the slot from it): 1.5 per stored value — one packed fma per two rows, one max each; the address is a
+                // wave-uniform row pointer walked by the scalar unit plus a fixed lane offset (global_store saddr form, written as
+                // asm because the compiler renders the same C as 64-bit vector adds: 5 VALU per value, trace build: 37k-cycle epilogues).
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
+                const unsigned voff = (unsigned)(4 * hh * a.y_cs + a.y_co + co) * 4u;
+                const unsigned long long yb = (unsigned long long)ybase;
+                unsigned long long rowp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(yb >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)yb);
+                const unsigned long long row1 = (unsigned long long)a.y_cs * 4u, row5 = row1 * 5u;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 v = __builtin_elementwise_fma(f32x2{acc[m][nn][r], acc[m][nn][r + 1]}, sc2, sh2);
+                        const float v0 = fmaxf(v.x, lo), v1 = fmaxf(v.y, lo);
+                        // ("+s": the pointer is walked between the stores, not computed 128 times up front and spilled)
+                        asm volatile("global_store_dword %1, %2, %0" : "+s"(rowp) : "v"(voff), "v"(v0) : "memory");
+                        rowp += row1;
+                        asm volatile("global_store_dword %1, %2, %0" : "+s"(rowp) : "v"(voff), "v"(v1) : "memory");
+                        rowp += (r & 3) == 2 ? row5 : row1;      // rows 0..3, 8..11, 16..19, 24..27 (+4 for lane half 1), next sub-tile at 32
+                    }
+            } else {
+                unsigned off = (unsigned)(4 * hh * a.y_cs + a.y_co + co);          // walks the rows 0..3, 8..11, ... of each sub-tile: +1 +1 +1 +5
+                unsigned roff = (unsigned)(4 * hh * a.res_cs + a.res_co + co);     // the same walk over the residual
+                int rows_left = cvalid ? (int)min(total_pix - wpix0 - 4 * hh, 1L << 20) : 0;   // rows of this lane half that exist
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    // keep the walk a walk (else: 128 hoisted row offsets / predicates, spilled)
+                    asm volatile("" : "+v"(off), "+v"(roff), "+v"(rows_left));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[m][nn][r] * sc + sh;
+                        const int step = (r & 3) == 3 ? 5 : 1;
+                        if (m * 32 + (r & 3) + 8 * (r >> 2) < rows_left) {
+                            if (a.res_mode == 1) v += rbase[roff];
+                            ybase[off] = fmaxf(v, lo);
+                        }
+                        off += step * a.y_cs;
+                        roff += step * a.res_cs;
+                    }
+                }
+            }
+        }
+    };
+    if (interior) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+#ifdef PW_TRACE
+    PW_STAMP(59);
+    if (tracing) {
+        trl[62] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 64; ++i) trc[i] = trl[i];
+    }
+#endif
+}
+
+template <int MT>
+static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 64 * MT;
+#ifdef PW_TRACE
+#ifndef PW_LDS_EXTRA
+#define PW_LDS_EXTRA 0
+#endif
+    constexpr int LDS_BYTES = 2 * BM * PST * 4 + 4 * 64 * 8 + PW_LDS_EXTRA;      // PW_LDS_EXTRA: experiments with one workgroup per CU
+    static DeviceOnce once;
+    int rc0 = once.run([]() {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_pw: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    });
+    if (rc0) return rc0;
+#else
+    constexpr int LDS_BYTES = 2 * BM * PST * 4;       // 40 KB (MT 4) / 20 KB (MT 2): under the 64 KB a kernel gets without an attribute
+#endif
+    ConvProblem& p = a.p[0];
+    p.tile_begin = 0;
+    p.tiles_h = p.tiles_w = 0;
+    const long tiles = (p.total_pix + BM - 1) / BM;
+    a.total_tiles = (int)tiles;
+    a.grid_y = a.cout_pad / 128;
+    hipLaunchKernelGGL(conv_pw_kernel<MT>, dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y)), dim3(256), LDS_BYTES, st, a);
+    return check_launch("conv_pw");
+}
+
+// mt = 4 | 2.  The caller (conv_igemm.hip: run) has filled the problem, views, epilogue options and cout_pad.
+int launch_pw(ConvArgs& a, int mt, hipStream_t st) {
+    const ConvProblem& p = a.p[0];
+    if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws || a.ksplit > 1 || a.res_mode == 2)
+        return fail(CMK_EINVAL, "conv_pw: one problem, no input affine / input ReLU / GroupNorm statistics / split-K / upsampled residual%s", "");
+    if ((a.Cin & 31) || (a.cout_pad & 127)) return fail(CMK_EINVAL, "conv_pw: needs Cin %% 32 == 0 and Cout > 224%s", "");
+    if (p.total_pix * a.x_cs * 4 >= (1L << 31)) return fail(CMK_EINVAL, "conv_pw: input view of 2 GiB or more%s", "");
+    if ((long)(64 * 4 + 8) * a.y_cs >= (1L << 30) || (long)(64 * 4 + 8) * a.res_cs >= (1L << 30)) return fail(CMK_EINVAL, "conv_pw: output row too wide%s", "");
+    if (mt == 4) return launch_pw_mt<4>(a, st);
+    if (mt == 2) return launch_pw_mt<2>(a, st);
+    return fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
+}
+
+}  // namespace cmk

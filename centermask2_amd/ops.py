@@ -288,6 +288,8 @@ def _tune(descs, n, key) -> None:
     cands = [(wm, sc, wn, sk) for wn in range(1, 8) for wm in (1, 2) for sc in (16, 32) for sk in sks]
     if small and d0.ksize == 3:
         cands += [(7, 32, wn, sk) for wn in (1, 2, 4) for sk in sks]      # gather form
+    if d0.ksize == 1:
+        cands += [(8, 32, 4, 1), (8, 32, 2, 1)]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
     if ALLOW_WINOGRAD:
         cands += [(5, 16, 2, 1)]                  # fused Winograd F(2x2,3x3)
         cands += [(6, 16, 1, 1), (6, 16, 2, 1)]   # fused Winograd F(4x4,3x3): map tiles / pairs of RoI maps (the library rejects what does not apply)
@@ -719,7 +721,7 @@ def kernel_source_hash() -> str:
     import os
     h = hashlib.sha1()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-    for f in ("conv_args.hpp", "conv_igemm.hip", "conv_wino6.hip"):
+    for f in ("conv_args.hpp", "conv_igemm.hip", "conv_wino6.hip", "conv_pw.hip"):
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:12]
 
@@ -736,6 +738,8 @@ def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) 
         wgs = sum(cd(n, 2) for n, h, w in shapes) if wn == 2 else sum(n * cd(h, 12) * cd(w, 40) for n, h, w in shapes)
         return float(wgs * cd(cout, 32) * (cin_pad // 8) * 144 * 4096)
     cout_pad = _lib.load().cmk_conv_cout_pad(cout)
+    if wm == 8:      # workgroup = 64*wn pixels x 128 couts
+        return float(sum(cd(n * h * w, 64 * wn) for n, h, w in shapes)) * (64 * wn) * cout_pad * cin_pad * 2.0
     if wm not in (1, 2):                      # cost-model / gather / split-K variants: geometry of the smallest tile
         wm, sc = 1, (32 if taps == 1 else 16)
     if taps == 9 and tuple(tv[:1]) != (7,):
@@ -757,6 +761,8 @@ def _kernel_name(taps, stride, tv, aff=False) -> str:
     if tv[0] == 6:
         return "conv_wino6_kernel<{}, {}>".format("true" if aff else "false", 1 if tv[2] == 2 else 0)
     wm, sc, wn = tv[:3]
+    if wm == 8:
+        return "conv_pw_kernel<{}>".format(wn)
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)
     return "conv_igemm_kernel<{}, {}, {}, {}, {}, false>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)

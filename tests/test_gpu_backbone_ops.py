@@ -223,6 +223,57 @@ def test_conv_stride2_and_1x1_variants(dev):
             _close(y.nchw(), ref)
 
 
+PW_CASES = [(2, 13, 19, 96, 256), (1, 25, 40, 2144, 1024), (1, 16, 16, 64, 320), (3, 9, 7, 32, 225), (1, 64, 64, 768, 256), (2, 10, 13, 160, 512)]
+
+
+@pytest.mark.parametrize("mt", [4, 2])
+@pytest.mark.parametrize("case", PW_CASES)
+def test_conv_pointwise_kernel(dev, case, mt):
+    """conv_pw (tune_wm 8): the 1x1 GEMM kernel with the weights fetched straight into registers, both workgroup heights; ragged pixel
+    counts, Cout that is not a multiple of the 128-cout tile; equal to conv_igemm bit for bit (same K and accumulation order)."""
+    n, h, w, cin, cout = case
+    x = _rand((n, cin, h, w), 61)
+    wt = _rand((cout, cin, 1, 1), 62, (2.0 / cin) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(63)) + 0.5
+    shift = _rand((cout,), 64, 0.1)
+    ref = F.relu(F.conv2d(x, wt, None) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    rc, y = _run_variant(dev, x, wt, scale, shift, (8, 32, mt))
+    assert rc == 0
+    _close(y.nchw(), ref)
+    rc0, y0 = _run_variant(dev, x, wt, scale, shift, (1, 32, 2))
+    assert rc0 == 0 and torch.equal(y.t, y0.t)
+
+
+def test_conv_pointwise_kernel_views_residual_partial_relu(dev, cmk_lib):
+    """Channel views on both sides, a same-size residual, ReLU on the first channels only; then the requests the kernel refuses."""
+    import ctypes
+    from centermask2_amd import _lib
+    n, h, w, cin, cout = 2, 17, 19, 64, 288
+    big = _rand((n, h, w, 160), 65).to(dev)
+    wt = _rand((cout, cin, 1, 1), 66, 0.1)
+    res = _rand((n, h, w, cout + 16), 67).to(dev)
+    pc = ops.PackedConv(wt, torch.rand(cout, generator=torch.Generator().manual_seed(68)) + 0.5, _rand((cout,), 69, 0.1), dev)
+    xin = big[..., 32:96].permute(0, 3, 1, 2).cpu()
+    ref = F.conv2d(xin, wt) * pc.scale.cpu().view(1, -1, 1, 1) + pc.shift.cpu().view(1, -1, 1, 1) + res[..., 16:].permute(0, 3, 1, 2).cpu()
+    ref[:, :100] = F.relu(ref[:, :100])
+    for mt in (4, 2):
+        out = torch.full((n, h, w, 400), -7.0, device=dev)
+        d = (_lib.ConvDesc * 1)()
+        ops._fill_desc(d[0], View(big, 32, cin), pc, View(out, 64, cout), False, 100, View(res, 16, cout), False, False)
+        d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 8, 32, mt
+        assert cmk_lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) == 0, cmk_lib.cmk_last_error()
+        torch.cuda.synchronize()
+        _close(out[..., 64:64 + cout].permute(0, 3, 1, 2), ref)
+        assert float(out[..., :64].max()) == -7.0 and float(out[..., 64 + cout:].min()) == -7.0   # neighbours untouched
+    # refused: a 3x3 conv, Cout <= 224, Cin % 32 != 0, a tile height that does not exist
+    x = _rand((1, 48, 8, 8), 70)
+    for wt_, tv in ((_rand((256, 48, 3, 3), 71), (8, 32, 4)), (_rand((128, 64, 1, 1), 72), (8, 32, 4)), (_rand((256, 48, 1, 1), 73), (8, 32, 4)),
+                    (_rand((256, 64, 1, 1), 74), (8, 32, 3))):
+        xx = x if wt_.shape[1] == 48 else _rand((1, 64, 8, 8), 75)
+        rc, _ = _run_variant(dev, xx, wt_, None, None, tv)
+        assert rc != 0, (tuple(wt_.shape), tv)
+
+
 WINO6_CASES = [(2, 37, 45, 64, 128), (1, 16, 16, 256, 256), (1, 25, 40, 224, 224), (2, 14, 14, 256, 80), (1, 100, 160, 32, 5),
                (1, 12, 40, 128, 32), (1, 13, 41, 48, 33), (3, 5, 3, 32, 64), (1, 50, 80, 192, 192)]
 

@@ -1,0 +1,22 @@
+#!/bin/bash
+# PMC passes of ONE 1x1 conv shape with a forced variant: tools/pmc_pw.sh <tag> H W Cin Cout wm wn  (on the GPU box, from the repo root)
+TAG=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+i=0
+for SET in "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_COEXEC_CYCLES" \
+           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --output-format csv --pmc $SET -d $OUT/p$i -o c -- python3 $ROOT/tools/prof_pw.py "$@" 2 > /dev/null 2> $OUT/p$i.err || tail -2 $OUT/p$i.err
+done
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("$OUT/p*/c_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "conv_pw" in r["Kernel_Name"] or "conv_igemm" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(acc): print("%-32s %.4g  (n=%d)" % (k, sum(acc[k]) / len(acc[k]), len(acc[k])))
+PY
+rm -rf $OUT/p*/c_kernel_trace.csv

@@ -1,17 +1,20 @@
 """Is a conv kernel clock/power-limited?  Runs one conv shape back to back for a few seconds while sampling rocm-smi (power, sclk).
-usage: power_probe.py H W Cin Cout wm [seconds]"""
+usage: power_probe.py H W Cin Cout wm[:wn] [seconds]     (wm 1 or 8 with :wn = a 1x1 conv with that variant forced)"""
 import sys, os, ctypes, subprocess, threading, time, re
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from centermask2_amd import ops, _lib
 from centermask2_amd.ops import View
-h, w, cin, cout, wm = [int(v) for v in sys.argv[1:6]]
+h, w, cin, cout = [int(v) for v in sys.argv[1:5]]
+wm, _, wn = sys.argv[5].partition(":")
+wm, wn = int(wm), (int(wn) if wn else 0)
 secs = float(sys.argv[6]) if len(sys.argv) > 6 else 4.0
 dev = torch.device("cuda:0"); lib = _lib.load()
-taps = 9 if wm != 1 else 1
+taps = 9 if wm not in (1, 8) else 1
 x = View(torch.randn((8, h, w, cin), device=dev)); pc = ops.PackedConv(torch.randn((cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1)) * 0.05, None, None, dev)
 y = View(torch.empty((8, h, w, cout), device=dev))
 d = (_lib.ConvDesc * 1)(); ops._fill_desc(d[0], x, pc, y, True, None, None, False, False)
+if taps == 1 and wn: d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = wm, 32, wn
 if taps == 9: d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = wm, 16, (1 if wm == 6 else 2)
 samples = []
 stop = False
