@@ -232,7 +232,7 @@ def _variant_on_menu(tv) -> bool:
     """(wm, sc, wn[, splitk]) names a kernel this library has (older tables may carry variants that were removed since)."""
     wm, sc, wn = tv[:3]
     sk = tv[3] if len(tv) > 3 else 1
-    return (wm in (1, 2, 5, 6, 7) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
+    return (wm in (1, 2, 5, 6, 7, 8) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
 
 
 def load_tuned(path: str) -> int:
