@@ -83,7 +83,7 @@ template <> struct W6G<1> {
         const int j = min(i, 4 * HC * 2 - 1); q = j & 1; const int cc = j >> 1; t = cc / HC; col = cc - t * HC;
     }
 };
-constexpr int W6_EX_FLOATS = 4 * 4 * 2 * 8 * 64;       // epilogue exchange: [src wave][dst wave][reg of the round][value][lane] = 64 KiB
+constexpr int W6_EX_FLOATS = 4 * 4 * 2 * 8 * 64;       // epilogue exchange: [src wave][dst wave][value][lane][register pair of the round] = 64 KiB
 template <int GEO> constexpr int w6_lds_bytes() { return (2 * W6G<GEO>::WB * 16 > W6_EX_FLOATS * 4) ? 2 * W6G<GEO>::WB * 16 : W6_EX_FLOATS * 4; }
 #ifdef W6_ONE_WG     // experiment: one workgroup per CU (how fast is a workgroup without a partner?)
 template <int GEO> constexpr int w6_lds_alloc() { return 96 * 1024; }
@@ -433,115 +433,149 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     // (measured: 340 ns per store, 26 us of a 76 us workgroup).  Wait once here and hand the values over through an asm the pass
     // cannot see through: from now on they are plain register values.
     asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(sc), "+v"(sh) : : "memory");
-    float* ex = smem;
-    const bool do_relu = co < a.relu_upto;
+    // Everything below works on PAIRS of accumulator registers (r, r+1 = two tiles of the lane) with packed-fp32 instructions, and the
+    // stores of interior tiles take a wave-uniform (row, column) base from the scalar unit plus one lane offset per tile: a VALU instruction
+    // issued here waits for a gap in the MFMA stream of the other workgroup on the SIMD and takes the slot from it (trace: this epilogue
+    // ran 12.4 us next to a partner, 5.6 us alone), so the epilogue is priced in VALU instructions — 3x fewer than the scalar form.
+    f32x2* ex2 = reinterpret_cast<f32x2*>(smem);        // exchange: [src wave][dst wave][value 0..7][lane] pairs = 64 KiB
+    const float lo = co < a.relu_upto ? 0.f : __builtin_nanf("");      // max(v, NaN) = v: lanes without the ReLU
+    const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
+    auto fma2 = [](f32x2 x, float k, f32x2 y) { return __builtin_elementwise_fma(x, f32x2{k, k}, y); };
+    const bool want_stats = a.gn_ws != nullptr;
+    f32x2 gs2 = {0.f, 0.f}, gss2 = {0.f, 0.f};
     float gs = 0.f, gss = 0.f;
     float* yimg = P.y + (long)n * H * W * a.y_cs + a.y_co + co;
+    // scalar side of the store addresses: image base (the pair's first image for GEO 1) and the byte strides of one pixel / one row
+    unsigned long long ybase_s;
+    {
+        const unsigned long long yb = (unsigned long long)(P.y + (long)n * H * W * a.y_cs);
+        ybase_s = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(yb >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)yb);
+    }
+    const unsigned long long px_b = (unsigned long long)a.y_cs * 4u, rowskip_b = (unsigned long long)(W - 3) * a.y_cs * 4u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        float own[2][8];
+        f32x2 own[8];
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int r = 4 * dd + 2 * q + rr;
-                float v[8];
-                {
-                    const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-                    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-                    v[0] = m0 + s1 + s2;
-                    v[1] = d1 + 2.0f * d2;
-                    v[2] = s1 + 4.0f * s2;
-                    v[3] = d1 + 8.0f * d2 + m5;
-                    const float n0 = acc[6][r], n1 = acc[7][r], n2 = acc[8][r];
-                    if (halfB == 0) {      // b = 0, 1, 2
-                        const float t1 = n1 + n2, e1 = n1 - n2;
-                        v[4] = n0 + t1; v[5] = e1; v[6] = t1; v[7] = e1;
-                    } else {               // b = 3, 4, 5
-                        const float t2s = n0 + n1, e2 = n0 - n1;
-                        v[4] = t2s; v[5] = 2.0f * e2; v[6] = 4.0f * t2s; v[7] = 8.0f * e2 + n2;
-                    }
+            const int r0 = 4 * dd + 2 * q;
+            f32x2 v[8];
+            {
+                const f32x2 m0 = {acc[0][r0], acc[0][r0 + 1]}, m1 = {acc[1][r0], acc[1][r0 + 1]}, m2 = {acc[2][r0], acc[2][r0 + 1]},
+                            m3 = {acc[3][r0], acc[3][r0 + 1]}, m4 = {acc[4][r0], acc[4][r0 + 1]}, m5 = {acc[5][r0], acc[5][r0 + 1]};
+                const f32x2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                v[0] = m0 + s1 + s2;
+                v[1] = fma2(d2, 2.0f, d1);
+                v[2] = fma2(s2, 4.0f, s1);
+                v[3] = fma2(d2, 8.0f, d1) + m5;
+                const f32x2 n0 = {acc[6][r0], acc[6][r0 + 1]}, n1 = {acc[7][r0], acc[7][r0 + 1]}, n2 = {acc[8][r0], acc[8][r0 + 1]};
+                if (halfB == 0) {      // b = 0, 1, 2
+                    const f32x2 t1 = n1 + n2, e1 = n1 - n2;
+                    v[4] = n0 + t1; v[5] = e1; v[6] = t1; v[7] = e1;
+                } else {               // b = 3, 4, 5
+                    const f32x2 t2s = n0 + n1, e2 = n0 - n1;
+                    v[4] = t2s; v[5] = e2 + e2; v[6] = t2s * 4.0f; v[7] = fma2(e2, 8.0f, n2);
                 }
-                if (dd == wave) {
+            }
+            if (dd == wave) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) own[rr][k] = v[k];
-                } else {
+                for (int k = 0; k < 8; ++k) own[k] = v[k];
+            } else {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) ex[((((wave * 4 + dd) * 2 + rr) * 8 + k) << 6) + lane] = v[k];
-                }
+                for (int k = 0; k < 8; ++k) ex2[(((wave * 4 + dd) * 8 + k) << 6) + lane] = v[k];
             }
         }
         W6_STAMP();                                   // 44 / 47: round written
         __syncthreads();
         W6_STAMP();                                   // 45 / 48: round visible
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            // P[a][j]: rows 0..3 from waves 0..3 (values 0..3), row 4 = halves of waves 0, 1, row 5 = halves of waves 2, 3 (values 4..7)
-            float Pm[6][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { Pm[4][j] = 0.f; Pm[5][j] = 0.f; }
+        // P[a][j]: rows 0..3 from waves 0..3 (values 0..3), row 4 = halves of waves 0, 1, row 5 = halves of waves 2, 3 (values 4..7)
+        f32x2 Pm[6][4];
+        {
+            f32x2 part[4][4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float v[8];
+                f32x2 v[8];
                 if (s == wave) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = own[rr][k];
+                    for (int k = 0; k < 8; ++k) v[k] = own[k];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = ex[((((s * 4 + wave) * 2 + rr) * 8 + k) << 6) + lane];
+                    for (int k = 0; k < 8; ++k) v[k] = ex2[(((s * 4 + wave) * 8 + k) << 6) + lane];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { Pm[s][j] = v[j]; Pm[4 + (s >> 1)][j] += v[4 + j]; }
+                for (int j = 0; j < 4; ++j) { Pm[s][j] = v[j]; part[s][j] = v[4 + j]; }
             }
-            // this entry is accumulator register 4*wave + 2q + rr of lane half hh: tile m
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { Pm[4][j] = part[0][j] + part[1][j]; Pm[5][j] = part[2][j] + part[3][j]; }
+        }
+        f32x2 yv[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 s1 = Pm[1][j] + Pm[2][j], d1 = Pm[1][j] - Pm[2][j], s2 = Pm[3][j] + Pm[4][j], d2 = Pm[3][j] - Pm[4][j];
+            f32x2 y[4];
+            y[0] = Pm[0][j] + s1 + s2;
+            y[1] = fma2(d2, 2.0f, d1);
+            y[2] = fma2(s2, 4.0f, s1);
+            y[3] = fma2(d2, 8.0f, d1) + Pm[5][j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x2 t = __builtin_elementwise_fma(y[i], sc2, sh2);
+                t.x = fmaxf(t.x, lo);
+                t.y = fmaxf(t.y, lo);
+                yv[i][j] = t;
+            }
+        }
+        // the pair's entries are accumulator registers 4*wave + 2q, +1 of lane half hh: tiles m, m + 1
+        bool full[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
             const int m = 2 * q + rr + 8 * wave + 4 * hh;
             int mimg, mt, mtc;
             G::tile_of(m, mimg, mt, mtc);
             const int oh = oh0 + 4 * mt, ow = ow0 + 4 * mtc;
             const bool tile_ok = cvalid && m < G::TILES && n + mimg < P.N;
-            float* yp0 = yimg + (((long)mimg * H + oh) * W + ow) * a.y_cs;
-            float yv[4][4];
+            full[rr] = tile_ok && oh + 4 <= H && ow + 4 <= W;
+            if (full[rr]) {                             // interior tile: 16 stores, no per-store predicate, no vector address arithmetic
+                const unsigned voff = (unsigned)((((mimg * H + oh) * W + ow) * a.y_cs + a.y_co + co) * 4);
+                unsigned long long sp = ybase_s;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float s1 = Pm[1][j] + Pm[2][j], d1 = Pm[1][j] - Pm[2][j], s2 = Pm[3][j] + Pm[4][j], d2 = Pm[3][j] - Pm[4][j];
-                float y[4];
-                y[0] = Pm[0][j] + s1 + s2;
-                y[1] = d1 + 2.0f * d2;
-                y[2] = s1 + 4.0f * s2;
-                y[3] = d1 + 8.0f * d2 + Pm[5][j];
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = y[i] * sc + sh;
-                    if (do_relu) v = fmaxf(v, 0.f);
-                    yv[i][j] = v;
-                }
-            }
-            if (tile_ok) {
-                if (oh + 4 <= H && ow + 4 <= W) {           // interior tile: 16 stores, no per-store predicate
+                    for (int j = 0; j < 4; ++j) {
+                        const float val = rr ? yv[i][j].y : yv[i][j].x;
+                        // ("+s": the pointer is walked between the stores, not computed 16 times up front)
+                        asm volatile("global_store_dword %1, %2, %0" : "+s"(sp) : "v"(voff), "v"(val) : "memory");
+                        sp += j == 3 ? rowskip_b : px_b;
+                    }
+            } else if (tile_ok) {
+                float* yp0 = yimg + (((long)mimg * H + oh) * W + ow) * a.y_cs;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            yp0[((long)i * W + j) * a.y_cs] = yv[i][j];
-                            gs += yv[i][j];
-                            gss = fmaf(yv[i][j], yv[i][j], gss);
+                    for (int j = 0; j < 4; ++j)
+                        if (oh + i < H && ow + j < W) {
+                            const float val = rr ? yv[i][j].y : yv[i][j].x;
+                            yp0[((long)i * W + j) * a.y_cs] = val;
+                            gs += val;
+                            gss = fmaf(val, val, gss);
                         }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (oh + i < H && ow + j < W) {
-                                yp0[((long)i * W + j) * a.y_cs] = yv[i][j];
-                                gs += yv[i][j];
-                                gss = fmaf(yv[i][j], yv[i][j], gss);
-                            }
-                }
             }
+        }
+        if (want_stats) {                               // whole tiles: packed, masked by tile
+            const f32x2 mask = {full[0] ? 1.f : 0.f, full[1] ? 1.f : 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 t = yv[i][j] * mask;
+                    gs2 += t;
+                    gss2 = __builtin_elementwise_fma(t, yv[i][j], gss2);
+                }
         }
         W6_STAMP();                                   // 46 / 49: round stored
         if (q == 0) __syncthreads();                        // the exchange buffer is reused by round 1
     }
+    gs += gs2.x + gs2.y;
+    gss += gss2.x + gss2.y;
     // fused GroupNorm statistics of the NEXT layer's normalisation (fcos.py:182-186): one {sum, sumsq} record per
     // (spatial tile, wave, group)
 #ifdef W6_TRACE
