@@ -30,6 +30,8 @@
 //
 // Reference call sites replaced: the same 3x3 stride-1 convs as the 2x2 kernel (vovnet.py:205-219, d2 FPN outputs, fcos.py:169-200,
 // sam.py:58-70, maskiou_head.py:81-88).
+#include <type_traits>
+
 #include "conv_args.hpp"
 
 #ifndef W6_TRACE_EVERY
@@ -247,6 +249,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     const f32x4* wl = sW + w6_slot<GEO>(hh, (GEO == 1 ? 4 * m_img : 0) + m_t, 0, 4 * m_tc);
     const f32x4* wA = wl + rowA * W6_AP;
     const f32x4* wB = wl + rowB * W6_AP;
+    const f32x4* wBa = wB + (halfB ? G::CK : 0);                // see rdB
+    const f32x4* wB3 = wB + (halfB ? 1 : 3 * G::CK);
     // U image: [chunk][cout tile][wave][9 slots][lane 64][4 floats]; slot k < 6: frequency (rowA, k); k >= 6: (rowB, 3*halfB + k - 6);
     // lane = 32*hh + li holds channels 8*chunk + 4*hh .. +3 of output channel 32*tile + li
     const float* u_wave = a.w + ((long)by * 4 + wave) * (9 * 256);       // wave-uniform: the loads take it as a scalar base, lane * 16 B as offset
@@ -331,10 +335,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
         else         { x.x0 = w2[K * 2]; x.x1 = w2[2 * K * 2]; x.x2 = w2[3 * K * 2]; x.x3 = w2[1 * 2]; x.x4 = w2[(K + 1) * 2]; }
         return x;
     };
-    auto rdB = [&](const f32x4* wrow, int h) {       // row B: which half is wave-uniform; kept a branch (the empty asm) so that only one runs
+    // row B: which half is wave-uniform.  With A = row + (second half ? K : 0) both halves read A[0], A[K], A[2K], A[1] and one more sample,
+    // A[3K] or A[1-K]: two address registers set up once (a branch between the two offset sets cost 22 VALU instructions per period in
+    // address arithmetic and moves, each of which takes a slot from the matrix pipe)
+    auto rdB = [&](const f32x4* wa, const f32x4* w3, int h) {
+        const f32x2* a2 = reinterpret_cast<const f32x2*>(wa) + h;
         X5 x;
-        if (halfB == 0) { asm volatile("" ::: "memory"); x = rd(wrow, false, h); }
-        else            { asm volatile("" ::: "memory"); x = rd(wrow, true, h); }
+        constexpr int K = G::CK;
+        x.x0 = a2[0]; x.x1 = a2[K * 2]; x.x2 = a2[2 * K * 2]; x.x3 = reinterpret_cast<const f32x2*>(w3)[h]; x.x4 = a2[1 * 2];
         return x;
     };
     auto mm = [&](const f32x2 v0, const f32x2 v1, const f32x2 v2, int h, int sbuf, int abase) {
@@ -359,9 +367,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
         mm(v0, v1, v2, h, 2, 6);
     };
     W6_STAMP();                                       // 1: prologue done
-    for (int c = 0; c < nchunks; ++c) {
-        const int wcur = (c & 1) * W6_WB;
-        f32x4* wnext = sW + ((c + 1) & 1) * W6_WB;
+    // two periods per trip: the W buffer of a period is then a compile-time offset of every LDS instruction (the parity as a register cost
+    // vector adds per period)
+    auto period = [&](const int c, auto parity) {
+        constexpr int wcur = decltype(parity)::value * W6_WB;
+        f32x4* wnext = sW + (1 - decltype(parity)::value) * W6_WB;
         const int step = c * 3;
 #if !(W6_ABL & 8)
         __syncthreads();
@@ -401,16 +411,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
         load_U(min(step + 3, total_steps - 1), 0);
         if (AHEAD) xb = rd(wA + wcur, true, 1); else xa = rd(wA + wcur, true, 0);
         half_step(xa, true, 0, 1, 3);
-        if (AHEAD) xa = rdB(wB + wcur, 0); else xb = rd(wA + wcur, true, 1);
+        if (AHEAD) xa = rdB(wBa + wcur, wB3 + wcur, 0); else xb = rd(wA + wcur, true, 1);
         half_step(xb, true, 1, 1, 3);
         W6_STAMP_AT(55);                              // step 1 issued
         W6_FENCE;
         load_U(min(step + 4, total_steps - 1), 1);
-        if (AHEAD) xb = rdB(wB + wcur, 1); else xa = rdB(wB + wcur, 0);
+        if (AHEAD) xb = rdB(wBa + wcur, wB3 + wcur, 1); else xa = rdB(wBa + wcur, wB3 + wcur, 0);
         half_stepB(xa, 0);
-        if (!AHEAD) xb = rdB(wB + wcur, 1);
+        if (!AHEAD) xb = rdB(wBa + wcur, wB3 + wcur, 1);
         half_stepB(xb, 1);
         W6_STAMP_AT(56);                              // step 2 issued
+    };
+    for (int c = 0; c < nchunks; c += 2) {        // nchunks is even: Cin is a multiple of 16 (validate)
+        period(c, std::integral_constant<int, 0>{});
+        period(c + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------------------
