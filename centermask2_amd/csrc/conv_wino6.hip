@@ -199,8 +199,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) okm |= ((iw >= 0 && iw < W && ih0 + i >= 0 && ih0 + i < H) ? 1u : 0u) << i;
     }
-    const float* aff_s = AFF ? P.in_scale + (long)min(n + p_img, P.N - 1) * a.Cin + p_q * 4 : nullptr;
-    const float* aff_b = AFF ? P.in_shift + (long)min(n + p_img, P.N - 1) * a.Cin + p_q * 4 : nullptr;
+    // scale/shift of the fused input affine: wave-uniform base (per chunk) + one 32-bit lane offset (two 64-bit lane pointers cost the
+    // variant the registers it does not have)
+    const unsigned aff_off = AFF ? (unsigned)(min(n + p_img, P.N - 1) * a.Cin + p_q * 4) : 0u;
     const f32x2 five = {5.0f, 5.0f};                   // the one transform coefficient that is not an inline constant: an SGPR pair
     f32x4 d[6];
     f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
@@ -208,21 +209,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) d[i] = w6_buffer_load(rsrc, voff0 + i * row_bytes, chunk * 32, 0);
         if (AFF) {
-            in_sc = *reinterpret_cast<const f32x4*>(aff_s + chunk * 8);
-            in_sh = *reinterpret_cast<const f32x4*>(aff_b + chunk * 8);
+            in_sc = *reinterpret_cast<const f32x4*>(P.in_scale + chunk * 8 + aff_off);
+            in_sh = *reinterpret_cast<const f32x4*>(P.in_shift + chunk * 8 + aff_off);
         }
     };
     const int p_dst = w6_slot<GEO>(p_q, (GEO == 1 ? 4 * p_img : 0) + p_t, 0, p_col);
     auto pass1 = [&](f32x4* wbuf) {
         if (AFF) {
+            // relu(x * s + b), and 0 for a sample outside the image (relu(0 * s + b) != 0): 2 packed fma per row, then ONE med3 per value —
+            // med3(v, 0, +inf) = max(v, 0), med3(v, 0, 0) = 0 — with the row's third operand made from the mask bit
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                f32x4 v = d[i];
-                const bool k = (okm >> i) & 1u;
-                v.x = fmaxf(v.x * in_sc.x + in_sh.x, 0.f); v.y = fmaxf(v.y * in_sc.y + in_sh.y, 0.f);
-                v.z = fmaxf(v.z * in_sc.z + in_sh.z, 0.f); v.w = fmaxf(v.w * in_sc.w + in_sh.w, 0.f);
-                v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
-                d[i] = v;
+                const float kinf = ((okm >> i) & 1u) ? __builtin_inff() : 0.f;
+                const f32x4 v = __builtin_elementwise_fma(d[i], in_sc, in_sh);
+                d[i] = f32x4{__builtin_amdgcn_fmed3f(v.x, 0.f, kinf), __builtin_amdgcn_fmed3f(v.y, 0.f, kinf),
+                             __builtin_amdgcn_fmed3f(v.z, 0.f, kinf), __builtin_amdgcn_fmed3f(v.w, 0.f, kinf)};
             }
         }
         f32x2* dst = reinterpret_cast<f32x2*>(wbuf + p_dst);
