@@ -643,6 +643,9 @@ static int launch_wino6_geo(ConvArgs& a, hipStream_t st) {
 
 // geo 0: 12x40-pixel tiles of one image; geo 1: pairs of whole maps of at most 16 rows x 14 columns (one problem, no fused GN statistics)
 int launch_wino6(ConvArgs& a, int geo, hipStream_t st) {
+    for (int i = 0; i < a.nprob; ++i)       // the epilogue's stores take a 32-bit byte offset inside the output image (GEO 1: inside a pair of images)
+        if ((long)(geo == 0 ? 1 : 2) * a.p[i].H * a.p[i].W * a.y_cs * 4 >= (1L << 32))
+            return fail(CMK_EINVAL, "conv_wino6: an output image of 4 GiB or more%s", "");
     if (geo == 0) return launch_wino6_geo<0>(a, st);
     if (a.nprob != 1 || a.p[0].H > 16 || a.p[0].W > 14 || a.gn_ws)
         return fail(CMK_EINVAL, "conv_wino6: the RoI-pair geometry takes one problem of maps up to 16x14 and produces no GroupNorm statistics%s", "");
