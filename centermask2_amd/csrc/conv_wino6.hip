@@ -207,7 +207,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
     auto load_D = [&](int chunk) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = w6_buffer_load(rsrc, voff0 + i * row_bytes, chunk * 32, 0);
+#ifndef W6_HALO_AUX
+#define W6_HALO_AUX 0          // cache policy of the halo loads (experiments: 1 sc0, 2 nt, 16 sc1)
+#endif
+        for (int i = 0; i < 6; ++i) d[i] = w6_buffer_load(rsrc, voff0 + i * row_bytes, chunk * 32, W6_HALO_AUX);
         if (AFF) {
             in_sc = *reinterpret_cast<const f32x4*>(P.in_scale + chunk * 8 + aff_off);
             in_sh = *reinterpret_cast<const f32x4*>(P.in_shift + chunk * 8 + aff_off);
