@@ -52,7 +52,11 @@ typedef struct {
      * identical across variants (the K order per output does not depend on the tile).
      * tune_wm == 7 (with tune_wn in {1,2,4}) selects the gather form of a 3x3 conv (stride 1|2): a flattened-pixel GEMM whose K walks
      * 9 taps x Cin/16 chunks, each A row gathered per tap — for maps too small to fill the spatial tiles (the 14->7 maskiou conv
-     * maskiou_head.py:84, P6/P7 fpn.py:32-35); same K order, so again bitwise identical to the tiled variants. */
+     * maskiou_head.py:84, P6/P7 fpn.py:32-35); same K order, so again bitwise identical to the tiled variants.
+     * tune_wm == 8 (with tune_wn in {4,2}) selects the pointwise GEMM kernel (conv_pw.hip) for a 1x1 conv with Cout > 224, Cin % 32 == 0,
+     * no fused input affine / input ReLU / upsampled residual / split-K: 64*tune_wn pixels x 128 output channels per workgroup, weights
+     * fetched straight into registers (the packed layout is the same); again the same bits as the tiled variants.  It is also the
+     * untuned default for such convs when they make at least 256 workgroups (vovnet.py:222-236 aggregation convs, the deconv). */
     int tune_wm; int tune_sc; int tune_wn;
     /* tune_wm == 5 selects the fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual; the default for such convs when w_wino
      * is given): same fp32 arithmetic on the matrix pipe with 2.25x fewer multiplies; results differ from the direct kernel by fp32
