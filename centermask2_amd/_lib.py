@@ -28,6 +28,7 @@ class ConvDesc(Structure):
         ("splitk", c_int), ("splitk_ws", c_void_p),
         ("gn_ws", c_void_p), ("gn_groups", c_int),
         ("w_wino6", c_void_p),
+        ("pool_ws", c_void_p),
     ]
 
 
@@ -42,6 +43,8 @@ SIGNATURES = {
     "cmk_last_error": (c_char_p, []),
     "cmk_conv2d_nhwc": (c_int, [POINTER(ConvDesc), c_void_p]),
     "cmk_conv2d_nhwc_multi": (c_int, [POINTER(ConvDesc), c_int, c_void_p]),
+    "cmk_conv_pool_rows": (c_int, [POINTER(ConvDesc)]),
+    "cmk_ese_gate_pooled": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cmk_conv_packed_floats": (c_int64, [c_int, c_int, c_int]),
     "cmk_conv_cout_pad": (c_int, [c_int]),
     "cmk_wino_packed_floats": (c_int64, [c_int, c_int]),

@@ -36,6 +36,7 @@ struct ConvArgs {
     double* gn_ws;     // Winograd 2-WG form: per (spatial tile, row parity, group) partial {sum, sum of squares} of the outputs (fused GroupNorm statistics)
     int gn_cpg, gn_groups;
     int ga_stride;     // gather form (GA): stride of the 3x3 conv whose taps are walked as 9x more K chunks
+    float* pool_ws;    // conv_pw only: per 32*MT-row block two records of Cout floats (cmk.h: cmk_conv_desc.pool_ws)
     int grid_y;   // N tiles; the N-tile index is the FASTEST block coordinate so the workgroups sharing an input tile run together (L2 reuse)
 };
 

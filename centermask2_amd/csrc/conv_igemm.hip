@@ -872,6 +872,7 @@ static int validate(const cmk_conv_desc* d) {
     if (d->res_mode < 0 || d->res_mode > 2 || (d->res_mode && !d->res)) return fail(CMK_EINVAL, "conv: bad residual%s", "");
     if ((d->in_scale == nullptr) != (d->in_shift == nullptr)) return fail(CMK_EINVAL, "conv: in_scale and in_shift come together%s", "");
     if (d->in_scale && d->ksize == 1 && ((long)d->H * d->W) % 256) return fail(CMK_EINVAL, "conv: input affine on a 1x1 conv needs H*W %% 256 == 0%s", "");
+    if (d->pool_ws && d->ksize != 1) return fail(CMK_EINVAL, "conv: pooled sums are for 1x1 convs%s", "");
     return CMK_OK;
 }
 
@@ -891,6 +892,22 @@ static int setup_gn(ConvArgs& a, const cmk_conv_desc* d) {
         return fail(CMK_EINVAL, "conv: fused GroupNorm statistics need relu_upto == 0 and a power-of-two group width <= 32%s", "");
     a.gn_ws = d->gn_ws; a.gn_cpg = cpg; a.gn_groups = d->gn_groups;
     return CMK_OK;
+}
+
+// The tile height (4 | 2) with which descriptor d runs on the pointwise GEMM kernel (conv_pw.hip), 0 if it does not: tune_wm 8 as given, or
+// the untuned default — 1x1 convs with enough pixels and output channels to fill the chip (measured 1.12-1.2x conv_igemm on every concat /
+// lateral / deconv shape of the model, tools/bench_pw.py), 256-pixel workgroups from 2 rounds on.
+static int pointwise_mt(const cmk_conv_desc* d, int n) {
+    const int cout32 = (d->Cout + 31) / 32;
+    const long total_pix = (long)d->N * d->H * d->W;
+    if (d->ksize != 1 || n != 1 || cout32 <= 7 || (d->Cin & 31) || d->in_scale || d->in_relu || d->res_mode == 2 || d->splitk > 1 || d->gn_ws ||
+        total_pix * d->x_cs * 4 >= (1L << 31))
+        return 0;
+    if (d->tune_wm == 8) return (d->tune_wn == 4 || d->tune_wn == 2) ? d->tune_wn : 0;
+    if (d->tune_wm || d->tune_sc || d->tune_wn) return 0;
+    const long ctiles = cdiv(cout32, 4);
+    const long wg2 = ((total_pix + 127) / 128) * ctiles, wg4 = ((total_pix + 255) / 256) * ctiles;
+    return wg2 >= 256 ? (wg4 >= 1024 ? 4 : 2) : 0;
 }
 
 static int run(const cmk_conv_desc* descs, int n, void* stream) {
@@ -934,6 +951,8 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     }
     a.ksplit = d->splitk > 1 ? d->splitk : 1;
     a.ws = d->splitk_ws;
+    if (d->pool_ws && !pointwise_mt(d, n)) return fail(CMK_EINVAL, "conv: pooled sums are produced by the pointwise GEMM kernel only (cmk_conv_pool_rows)%s", "");
+    a.pool_ws = d->pool_ws;
     if (d->tune_wm == 8) {                             // pointwise GEMM kernel (conv_pw.hip); tune_wn = accumulator rows per wave
         if (d->ksize != 1 || cout32 <= 7) return fail(CMK_EINVAL, "conv: pointwise variant needs a 1x1 conv with Cout > 224%s", "");
         a.cout_pad = cdiv(cout32, 4) * 128;
@@ -1003,16 +1022,9 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
             return wn == 4 ? launch<1, 1, 1, 4, 32, true>(a, gy, st) : wn == 2 ? launch<1, 1, 1, 2, 32, true>(a, gy, st)
                                                                                : launch<1, 1, 1, 1, 32, true>(a, gy, st);
         }
-        // 1x1 convs with enough pixels and output channels to fill the chip: the pointwise GEMM kernel (conv_pw.hip; measured 1.12-1.2x
-        // conv_igemm on every concat / lateral / deconv shape of the model, tools/bench_pw.py), 256-pixel workgroups from 2 rounds on
-        if (d->ksize == 1 && n == 1 && cout32 > 7 && !(d->Cin & 31) && !d->in_scale && !d->in_relu && d->res_mode != 2 && a.ksplit == 1 &&
-            a.p[0].total_pix * d->x_cs * 4 < (1L << 31)) {
-            const long ctiles = cdiv(cout32, 4);
-            const long wg2 = ((a.p[0].total_pix + 127) / 128) * ctiles, wg4 = ((a.p[0].total_pix + 255) / 256) * ctiles;
-            if (wg2 >= 256) {
-                a.cout_pad = (int)ctiles * 128;
-                return launch_pw(a, wg4 >= 1024 ? 4 : 2, st);
-            }
+        if (const int mt = pointwise_mt(d, n)) {
+            a.cout_pad = cdiv(cout32, 4) * 128;
+            return launch_pw(a, mt, st);
         }
         v = choose_variant(a, taps, d->stride, cout32);
     }
@@ -1045,6 +1057,12 @@ extern "C" int64_t cmk_wino_packed_floats(int Cout, int Cin) {
     return (int64_t)((Cin + 15) / 16) * ((Cout + 63) / 64) * 16 * 64 * 16;
 }
 
+extern "C" int cmk_conv_pool_rows(const cmk_conv_desc* d) {
+    if (!d) return 0;
+    const int mt = cmk::pointwise_mt(d, 1);
+    return (mt && (long)d->H * d->W >= 32 * mt) ? 32 * mt : 0;
+}
+
 extern "C" int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream) {
     int rc = cmk::validate(d);
     if (rc) return rc;
@@ -1061,7 +1079,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
             b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || b->w_wino6 != a->w_wino6 || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
-            b->gn_ws != a->gn_ws || b->gn_groups != a->gn_groups || b->splitk > 1)
+            b->gn_ws != a->gn_ws || b->gn_groups != a->gn_groups || b->splitk > 1 || b->pool_ws)
             return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
     }
     return run(descs, n, stream);

@@ -26,7 +26,8 @@ namespace cmk {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 pw_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
-template <int MT>
+// POOL: also leave the per-block sums of the stored values in a.pool_ws (the eSE average pool of the aggregation conv, cmk.h)
+template <int MT, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     constexpr int BM = 64 * MT;         // pixels per workgroup
     constexpr int ABUF = BM * PST;      // floats per LDS buffer (rows of 16 channels, pitch 20)
@@ -214,10 +215,20 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     float* ybase = P.y + wpix0 * a.y_cs;                                   // wave-uniform; rows are added to the lane offset below
     const float* rbase = a.res_mode == 1 ? a.res + wpix0 * a.res_cs : nullptr;
     const bool interior = a.res_mode == 0 && pix0 + BM <= total_pix && co0 + 64 <= a.Cout;
+    // POOL: this wave's 32*MT rows are block g of the flattened pixels; rows from `bnd` on belong to the next image
+    const long blk_g = (long)bx * 2 + wm;
+    int bnd = MT * 32;
+    if (POOL) {
+        const long hw = (long)P.Ho * P.Wo, first = blk_g * (MT * 32);
+        bnd = (int)min((long)(MT * 32), (first / hw + 1) * hw - first);
+    }
     auto epilogue = [&](auto interior_tag) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 pool2 = {0.f, 0.f};             // sums of this lane's stored values: rows before / from `bnd` (INTERIOR without a boundary: .x and .y are two halves of one sum)
+            float poolA = 0.f, poolB = 0.f;
             const int co = co0 + nn * 32 + li;
             const bool cvalid = INTERIOR || co < a.Cout;
             float sc = cvalid ? P.scale[co] : 0.f;
@@ -231,7 +242,6 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
                 // (and takes the slot from it): 1.5 per stored value — one packed fma per two rows, one max each; the address is a
                 // wave-uniform row pointer walked by the scalar unit plus a fixed lane offset (global_store saddr form, written as
                 // asm because the compiler renders the same C as 64-bit vector adds: 5 VALU per value, trace build: 37k-cycle epilogues).
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
                 const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
                 const unsigned voff = (unsigned)(4 * hh * a.y_cs + a.y_co + co) * 4u;
                 const unsigned long long yb = (unsigned long long)ybase;
@@ -244,12 +254,27 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
                     for (int r = 0; r < 16; r += 2) {
                         f32x2 v = __builtin_elementwise_fma(f32x2{acc[m][nn][r], acc[m][nn][r + 1]}, sc2, sh2);
                         const float v0 = fmaxf(v.x, lo), v1 = fmaxf(v.y, lo);
+                        if (POOL) pool2 += f32x2{v0, v1};
                         // ("+s": the pointer is walked between the stores, not computed 128 times up front and spilled)
                         asm volatile("global_store_dword %1, %2, %0" : "+s"(rowp) : "v"(voff), "v"(v0) : "memory");
                         rowp += row1;
                         asm volatile("global_store_dword %1, %2, %0" : "+s"(rowp) : "v"(voff), "v"(v1) : "memory");
                         rowp += (r & 3) == 2 ? row5 : row1;      // rows 0..3, 8..11, 16..19, 24..27 (+4 for lane half 1), next sub-tile at 32
                     }
+                if (POOL) {
+                    poolA = pool2.x + pool2.y;
+                    if (bnd < MT * 32) {            // an image ends inside this block (wave-uniform, rare): split the sum by row
+                        asm volatile("" ::: "memory");
+                        poolA = 0.f;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = fmaxf(acc[m][nn][r] * sc + sh, lo);
+                                if (m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < bnd) poolA += v; else poolB += v;
+                            }
+                    }
+                }
             } else {
                 unsigned off = (unsigned)(4 * hh * a.y_cs + a.y_co + co);          // walks the rows 0..3, 8..11, ... of each sub-tile: +1 +1 +1 +5
                 unsigned roff = (unsigned)(4 * hh * a.res_cs + a.res_co + co);     // the same walk over the residual
@@ -264,11 +289,21 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
                         const int step = (r & 3) == 3 ? 5 : 1;
                         if (m * 32 + (r & 3) + 8 * (r >> 2) < rows_left) {
                             if (a.res_mode == 1) v += rbase[roff];
-                            ybase[off] = fmaxf(v, lo);
+                            v = fmaxf(v, lo);
+                            ybase[off] = v;
+                            if (POOL) { if (m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < bnd) poolA += v; else poolB += v; }
                         }
                         off += step * a.y_cs;
                         roff += step * a.res_cs;
                     }
+                }
+            }
+            if (POOL) {                                   // the two lane halves hold different rows of the same cout
+                poolA += __shfl_xor(poolA, 32);
+                poolB += __shfl_xor(poolB, 32);
+                if (hh == 0 && co < a.Cout) {
+                    a.pool_ws[(blk_g * 2) * a.Cout + co] = poolA;
+                    a.pool_ws[(blk_g * 2 + 1) * a.Cout + co] = poolB;
                 }
             }
         }
@@ -284,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int MT>
+template <int MT, bool POOL>
 static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * MT;
 #ifdef PW_TRACE
@@ -294,7 +329,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int LDS_BYTES = 2 * BM * PST * 4 + 4 * 64 * 8 + PW_LDS_EXTRA;      // PW_LDS_EXTRA: experiments with one workgroup per CU
     static DeviceOnce once;
     int rc0 = once.run([]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_pw: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     });
     if (rc0) return rc0;
@@ -307,7 +342,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     const long tiles = (p.total_pix + BM - 1) / BM;
     a.total_tiles = (int)tiles;
     a.grid_y = a.cout_pad / 128;
-    hipLaunchKernelGGL(conv_pw_kernel<MT>, dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y)), dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_pw_kernel<MT, POOL>), dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y)), dim3(256), LDS_BYTES, st, a);
     return check_launch("conv_pw");
 }
 
@@ -319,8 +354,9 @@ int launch_pw(ConvArgs& a, int mt, hipStream_t st) {
     if ((a.Cin & 31) || (a.cout_pad & 127)) return fail(CMK_EINVAL, "conv_pw: needs Cin %% 32 == 0 and Cout > 224%s", "");
     if (p.total_pix * a.x_cs * 4 >= (1L << 31)) return fail(CMK_EINVAL, "conv_pw: input view of 2 GiB or more%s", "");
     if ((long)(64 * 4 + 8) * a.y_cs >= (1L << 30) || (long)(64 * 4 + 8) * a.res_cs >= (1L << 30)) return fail(CMK_EINVAL, "conv_pw: output row too wide%s", "");
-    if (mt == 4) return launch_pw_mt<4>(a, st);
-    if (mt == 2) return launch_pw_mt<2>(a, st);
+    if (a.pool_ws && (long)p.Ho * p.Wo < 32 * mt) return fail(CMK_EINVAL, "conv_pw: pooled sums need H*W >= the block of %s%ld rows", "", 32 * mt);
+    if (mt == 4) return a.pool_ws ? launch_pw_mt<4, true>(a, st) : launch_pw_mt<4, false>(a, st);
+    if (mt == 2) return a.pool_ws ? launch_pw_mt<2, true>(a, st) : launch_pw_mt<2, false>(a, st);
     return fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
 }
 

@@ -233,6 +233,51 @@ __global__ __launch_bounds__(256) void ese_fc_kernel(const float* __restrict__ w
     }
 }
 
+// The gate from the per-block sums the aggregation conv left behind (cmk_conv_desc.pool_ws): record 2g = rows of block g in the image of
+// its first pixel, 2g+1 = rows of block g in the next image.  Stage 1 (channel means) differs from ese_fc_kernel, stage 2 is the same.
+__global__ __launch_bounds__(256) void ese_fc_pooled_kernel(const float* __restrict__ rec, int rows, const float* __restrict__ fc_w,
+                                                           const float* __restrict__ fc_b, float* __restrict__ gate, int HW, int C) {
+    extern __shared__ float sm[];  // [parts][C] partials, then mean in row 0
+    const int n = blockIdx.y;
+    const int G = C >> 2;
+    const int parts = G >= 256 ? 1 : 256 / G;
+    const long p0 = (long)n * HW;
+    const long g0 = p0 / rows, g1 = (p0 + HW - 1) / rows;
+    const long first = (g0 * rows == p0) ? 2 * g0 : 2 * g0 + 1;          // the record of block g0 that holds this image's rows
+    for (int gi = threadIdx.x; gi < G * parts; gi += 256) {
+        const int g = gi % G, part = gi / G;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (part == 0) s = *reinterpret_cast<const f32x4*>(rec + first * C + g * 4);
+#pragma unroll 8
+        for (long k = g0 + 1 + part; k <= g1; k += parts) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(rec + 2 * k * C + g * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<f32x4*>(sm + part * C + g * 4) = s;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int part = 0; part < parts; ++part) s += sm[part * C + c];
+        sm[c] = s / (float)HW;   // row 0 is only read by its own thread above
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = blockIdx.x * 16 + wave; o < min(C, (int)(blockIdx.x + 1) * 16); o += 4) {
+        const float* wr = fc_w + (long)o * C;
+        float s = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+            s += wv.x * sm[c] + wv.y * sm[c + 1] + wv.z * sm[c + 2] + wv.w * sm[c + 3];
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            float v = s + fc_b[o] + 3.0f;
+            gate[(long)n * C + o] = fminf(fmaxf(v, 0.f), 6.f) / 6.0f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void ese_scale_kernel(const float* __restrict__ x, int x_cs, int x_co, const float* __restrict__ gate,
                                                        const float* __restrict__ idn, int id_cs, int id_co, float* __restrict__ y,
                                                        int y_cs, int y_co, int N, int HW, int C4) {
@@ -497,6 +542,16 @@ extern "C" int cmk_ese_gate(const float* x, int x_cs, int x_co, const float* fc_
     hipLaunchKernelGGL(ese_fc_kernel, dim3(cdiv(C, 16), N), dim3(256), lds1, (hipStream_t)stream, ws, fc_w, fc_b,
                        gate, HW, C, ws_chunks);
     return check_launch("ese_fc");
+}
+
+extern "C" int cmk_ese_gate_pooled(const float* pool_ws, int rows, const float* fc_w, const float* fc_b, float* gate, int N, int HW, int C, void* stream) {
+    if (!pool_ws || !fc_w || !fc_b || !gate) return fail(CMK_EINVAL, "ese_gate_pooled: null pointer%s", "");
+    if ((C & 3) || rows < 1 || HW < rows || N < 1) return fail(CMK_EINVAL, "ese_gate_pooled: bad shape (C %% 4, H*W >= rows)%s", "");
+    const int G = C >> 2;
+    const int parts = G >= 256 ? 1 : 256 / G;
+    hipLaunchKernelGGL(ese_fc_pooled_kernel, dim3(cdiv(C, 16), N), dim3(256), (size_t)parts * C * sizeof(float), (hipStream_t)stream, pool_ws, rows,
+                       fc_w, fc_b, gate, HW, C);
+    return check_launch("ese_fc_pooled");
 }
 
 extern "C" int cmk_ese_scale(const float* x, int x_cs, int x_co, const float* gate, const float* identity, int id_cs, int id_co, float* y,

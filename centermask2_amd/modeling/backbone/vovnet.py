@@ -240,7 +240,8 @@ class VoVNet(Backbone):
                     else:
                         ops.conv2d(src, P["{}_{}".format(mn, i)], dst, relu=True)
                     src, off = dst, off + blk.stage_ch
-                xt = ops.conv_out(View(cat), P[mn + "_concat"], relu=True)     # 1x1 over the un-materialised concat
+                pooled = []             # the aggregation conv leaves the eSE average pool's partial sums behind when its kernel can
+                xt = ops.conv_out(View(cat), P[mn + "_concat"], relu=True, pool=pooled)     # 1x1 over the un-materialised concat
                 if b + 1 < len(blocks):
                     nxt = torch.empty((n, h, w, blocks[b + 1].cat_ch), dtype=torch.float32, device=dev)
                     out = View(nxt, 0, blk.concat_ch)
@@ -248,13 +249,14 @@ class VoVNet(Backbone):
                     nxt = None
                     out = View(torch.empty((n, h, w, blk.concat_ch), dtype=torch.float32, device=dev))
                 fw, fb = P[mn + "_ese"]
+                gate = ops.ese_gate_pooled(pooled[0], fw, fb, n, h * w) if pooled else None
                 if nxt is None and not blk.identity and sname not in self._out_features and sname != self.stage_names[-1]:
                     # nobody but the next stage's max pool reads this output: max(x*g) == g*max(x) for the non-negative
                     # hsigmoid gate, so the scale pass (a full read+write of the largest map) is folded into the pool
-                    prev_gate = ops.ese_gate(xt, fw, fb)
+                    prev_gate = gate if gate is not None else ops.ese_gate(xt, fw, fb)
                     out = xt
                 else:
-                    ops.ese(xt, fw, fb, out, identity=inp if blk.identity else None)   # eSE then identity add (:327-330)
+                    ops.ese(xt, fw, fb, out, identity=inp if blk.identity else None, gate=gate)   # eSE then identity add (:327-330)
                 if nxt is not None:
                     cat, inp = nxt, out
             prev = out

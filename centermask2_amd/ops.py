@@ -5,6 +5,7 @@ NHWC float32; `View` is (NHWC tensor, channel offset, channels) so producers wri
 an OSA concat buffer.  Every function raises if the tensors are not on a GPU — there is no CPU fallback.
 """
 import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -192,6 +193,7 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
 
 
 # ---- tile-variant autotuning (host side; the library itself stays stateless) -----------------------------------
+FUSE_POOL = os.environ.get("CMK_FUSE_POOL", "1") != "0"      # eSE: average-pool partial sums from the aggregation conv's epilogue (A/B switch)
 PACK_WINO6 = True         # pack the F(4x4,3x3) weights too (4x the filter bank per 3x3 stride-1 conv)
 ALLOW_WINOGRAD = True     # let the tuner pick the Winograd F(2x2,3x3) kernel where it is faster (fp32, differs by rounding only)
 FORCE_VARIANT = None      # (wm, sc, wn[, splitk]) for every conv launched through the wrappers below (tests, A/B tools); None = table/tuner/default
@@ -351,11 +353,20 @@ def _problem_key(descs, n):
 
 
 def conv2d(x: View, pc: PackedConv, y: View, relu: bool = False, relu_upto: Optional[int] = None,
-           res: Optional[View] = None, res_upsample: bool = False, in_relu: bool = False) -> None:
+           res: Optional[View] = None, res_upsample: bool = False, in_relu: bool = False, pool: Optional[list] = None) -> None:
+    """pool: a list that receives (partial sums, rows per record) when the kernel this conv runs on also leaves the average-pool partial
+    sums of its output behind (cmk_conv_desc.pool_ws: the pointwise GEMM kernel, for the eSE gate); left empty otherwise."""
     lib = _lib.load()
     descs = (ConvDesc * 1)()
     _fill_desc(descs[0], x, pc, y, relu, relu_upto, res, res_upsample, in_relu)
     ws = _apply_tuning(descs, 1, _problem_key(descs, 1))      # split-K workspace (if any) stays referenced across the launch
+    if pool is not None and FUSE_POOL:
+        rows = lib.cmk_conv_pool_rows(ctypes.byref(descs[0]))
+        if rows > 0:
+            d = descs[0]
+            pws = torch.empty((2 * (-(-(d.N * d.H * d.W) // rows)), pc.cout), dtype=torch.float32, device=y.t.device)
+            d.pool_ws = pws.data_ptr()
+            pool.append((pws, rows))
     check(lib.cmk_conv2d_nhwc(ctypes.byref(descs[0]), _stream()), "cmk_conv2d_nhwc")
     del ws
 
@@ -530,17 +541,28 @@ def ese_gate(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor) -> torch.Tensor:
     return gate
 
 
-def ese(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor, y: View, identity: Optional[View] = None) -> None:
-    """y = x * hsigmoid(fc(mean_HW(x))) (+ identity)   (vovnet.py:255-260, :329-330)."""
+def ese_gate_pooled(pooled, fc_w: torch.Tensor, fc_b: torch.Tensor, n: int, hw: int) -> torch.Tensor:
+    """The same gate from the partial sums the producing conv left behind (conv2d(..., pool=[...])): no pass over the map."""
+    lib = _lib.load()
+    pws, rows = pooled
+    c = pws.shape[1]
+    gate = torch.empty((n, c), dtype=torch.float32, device=pws.device)
+    check(lib.cmk_ese_gate_pooled(pws.data_ptr(), rows, fc_w.data_ptr(), fc_b.data_ptr(), gate.data_ptr(), n, hw, c, _stream()), "cmk_ese_gate_pooled")
+    return gate
+
+
+def ese(x: View, fc_w: torch.Tensor, fc_b: torch.Tensor, y: View, identity: Optional[View] = None, gate: Optional[torch.Tensor] = None) -> None:
+    """y = x * hsigmoid(fc(mean_HW(x))) (+ identity)   (vovnet.py:255-260, :329-330).  gate: already computed (ese_gate_pooled)."""
     lib = _lib.load()
     _need_gpu(x.t, "ese")
     n, h, w = x.nhw
     hw, c = h * w, x.c
-    chunks = _ese_chunks(hw, c)
-    ws = torch.empty((n, chunks, c), dtype=torch.float32, device=x.t.device)
-    gate = torch.empty((n, c), dtype=torch.float32, device=x.t.device)
-    check(lib.cmk_ese_gate(x.t.data_ptr(), x.cs, x.co, fc_w.data_ptr(), fc_b.data_ptr(), gate.data_ptr(), ws.data_ptr(), chunks,
-                           n, hw, c, _stream()), "cmk_ese_gate")
+    if gate is None:
+        chunks = _ese_chunks(hw, c)
+        ws = torch.empty((n, chunks, c), dtype=torch.float32, device=x.t.device)
+        gate = torch.empty((n, c), dtype=torch.float32, device=x.t.device)
+        check(lib.cmk_ese_gate(x.t.data_ptr(), x.cs, x.co, fc_w.data_ptr(), fc_b.data_ptr(), gate.data_ptr(), ws.data_ptr(), chunks,
+                               n, hw, c, _stream()), "cmk_ese_gate")
     idp, idcs, idco = (identity.t.data_ptr(), identity.cs, identity.co) if identity is not None else (None, 0, 0)
     check(lib.cmk_ese_scale(x.t.data_ptr(), x.cs, x.co, gate.data_ptr(), idp, idcs, idco, y.t.data_ptr(), y.cs, y.co,
                             n, hw, c, _stream()), "cmk_ese_scale")

@@ -89,8 +89,16 @@ typedef struct {
      * [Cin/8][ceil(Cout/32)][wave 4][slot 9][lane 64][4 floats]: slot k < 6 is frequency (row = wave, column = k), slot k >= 6 is
      * (row = 4 + wave/2, column = 3*(wave%2) + k - 6); output channel = tile*32 + (lane & 31), input channel = chunk*8 + 4*(lane >> 5) + j. */
     const float* w_wino6;
+    /* optional fused average-pool partial sums of the (scaled, shifted, ReLU'd) OUTPUT, for the eSE gate of the OSA aggregation conv
+     * (vovnet.py:255-256 avg_pool over the conv the block just produced): only the pointwise GEMM kernel produces them — ask
+     * cmk_conv_pool_rows(d) first; it returns R > 0 (rows of flattened pixels per record) when this descriptor, as tuned, runs on that
+     * kernel and H*W >= R, else 0.  pool_ws then receives 2 * ceil(N*H*W / R) records of Cout floats: record 2g = the sum over the rows
+     * of block g (pixels gR .. gR+R-1) that belong to the image of the block's first pixel, record 2g+1 = the sum over its rows that
+     * belong to the next image (0 if none); every record is written.  cmk_ese_gate_pooled turns them into the gate.  NULL = off. */
+    float* pool_ws;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
+int cmk_conv_pool_rows(const cmk_conv_desc* d);
 /* Same conv applied to up to 5 inputs of different H x W in ONE launch (the FCOS towers/predictors share their weights
  * across the FPN levels, fcos.py:227-238).  All descriptors must share w, Cin, Cout, ksize, stride, views and flags and
  * carry no residual; x, y, N, H, W, scale, shift may differ. */
@@ -126,6 +134,9 @@ int cmk_ese_gate(const float* x, int x_cs, int x_co, const float* fc_w /* [C][C]
                  float* gate /* N*C */, float* ws, int ws_chunks, int N, int HW, int C, void* stream);
 int cmk_ese_scale(const float* x, int x_cs, int x_co, const float* gate, const float* identity, int id_cs, int id_co,
                   float* y, int y_cs, int y_co, int N, int HW, int C, void* stream);
+/* the gate from the partial sums the producing conv left in pool_ws (cmk_conv_desc.pool_ws; rows = cmk_conv_pool_rows of that conv):
+ * no pass over the map.  Fixed summation order. */
+int cmk_ese_gate_pooled(const float* pool_ws, int rows, const float* fc_w, const float* fc_b, float* gate, int N, int HW, int C, void* stream);
 
 /* ---- GroupNorm(32) + ReLU in place (fcos.py:182-186) ---------------------------------------------------------
  * ws: N * groups * gn_chunks * 2 doubles.                                                                    */

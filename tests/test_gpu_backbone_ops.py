@@ -274,6 +274,44 @@ def test_conv_pointwise_kernel_views_residual_partial_relu(dev, cmk_lib):
         assert rc != 0, (tuple(wt_.shape), tv)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256, 4), (3, 10, 13, 96, 512, 2), (3, 10, 13, 96, 512, 4), (2, 9, 15, 64, 320, 2), (5, 8, 9, 32, 256, 2)])
+def test_conv_pointwise_pooled_sums_and_ese_gate(dev, cmk_lib, case):
+    """The aggregation conv's fused average-pool partial sums (cmk_conv_desc.pool_ws) and the eSE gate made from them: images whose pixel
+    count is not a multiple of the block (records split at the image boundary), a ragged last block, Cout that is not a multiple of 128.
+    Reference: torch mean over the conv output and the reference's hsigmoid(fc(mean)) (vovnet.py:247-260)."""
+    import ctypes
+    from centermask2_amd import _lib
+    n, h, w, cin, cout, mt = case
+    x = _rand((n, cin, h, w), 81)
+    wt = _rand((cout, cin, 1, 1), 82, (2.0 / cin) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(83)) + 0.5
+    shift = _rand((cout,), 84, 0.1)
+    fc_w, fc_b = _rand((cout, cout), 85, 0.05), _rand((cout,), 86, 0.5)
+    ref = F.relu(F.conv2d(x, wt, None) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref_gate = F.relu6(F.linear(ref.mean(dim=(2, 3)), fc_w, fc_b) + 3.0) / 6.0
+    pc = ops.PackedConv(wt, scale, shift, dev)
+    y = View(torch.full((n, h, w, cout), -5.0, device=dev))
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], ops.as_view(x.to(dev)), pc, y, True, None, None, False, False)
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 8, 32, mt
+    rows = cmk_lib.cmk_conv_pool_rows(ctypes.byref(d[0]))
+    assert rows == 32 * mt
+    pws = torch.full((2 * (-(-(n * h * w) // rows)), cout), float("nan"), device=dev)
+    d[0].pool_ws = pws.data_ptr()
+    assert cmk_lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) == 0, cmk_lib.cmk_last_error()
+    torch.cuda.synchronize()
+    _close(y.nchw(), ref)
+    assert bool(torch.isfinite(pws).all())                       # every record is written
+    _close(pws.sum(0) / (n * h * w), ref.mean(dim=(0, 2, 3)), rel=1e-5)
+    gate = ops.ese_gate_pooled((pws, rows), fc_w.to(dev), fc_b.to(dev), n, h * w)
+    torch.cuda.synchronize()
+    _close(gate, ref_gate, rel=1e-5)
+    # a conv the pointwise kernel does not run: no pooled sums on offer, and asking for them anyway is an error
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 1, 32, 2
+    assert cmk_lib.cmk_conv_pool_rows(ctypes.byref(d[0])) == 0
+    assert cmk_lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
+
+
 WINO6_CASES = [(2, 37, 45, 64, 128), (1, 16, 16, 256, 256), (1, 25, 40, 224, 224), (2, 14, 14, 256, 80), (1, 100, 160, 32, 5),
                (1, 12, 40, 128, 32), (1, 13, 41, 48, 33), (3, 5, 3, 32, 64), (1, 50, 80, 192, 192)]
 

@@ -124,12 +124,15 @@ def test_end_to_end_800x1280_matches_reference(dev, model):
     for i in range(2):
         r, inst = g["img{}".format(i)], res[i]
         assert len(inst) == r["scores"].shape[0]
-        assert torch.equal(inst.pred_classes.cpu(), r["classes"]), "labels differ"
-        assert torch.equal(inst.locations.cpu(), r["locations"]), "ROI locations differ"
-        close(inst.pred_boxes.tensor, r["boxes"], 2e-5, "boxes")   # pixels: reg (1e-3 bar, checked above) x stride x scale
-        close(inst.scores, r["scores"], 1e-4, "scores")
-        close(inst.pred_masks, r["pred_masks"], 1e-3, "pred_masks")
-        close(inst.mask_scores, r["mask_scores"], 1e-3, "mask_scores")
+        # the same detections, labels and locations exact; their ORDER may differ only between scores closer than 1e-5 (the fixture's
+        # detections 8 and 9 of image 0 are 2.2e-6 apart — below the network's own fp32 noise; see match_detections)
+        pg = match_detections(r["scores"], r["classes"], r["locations"], inst.scores, inst.pred_classes, inst.locations, tol=1e-5).to(dev)
+        assert torch.equal(inst.pred_classes[pg].cpu(), r["classes"]), "labels differ"
+        assert torch.equal(inst.locations[pg].cpu(), r["locations"]), "ROI locations differ"
+        close(inst.pred_boxes.tensor[pg], r["boxes"], 2e-5, "boxes")   # pixels: reg (1e-3 bar, checked above) x stride x scale
+        close(inst.scores[pg], r["scores"], 1e-4, "scores")
+        close(inst.pred_masks[pg], r["pred_masks"], 1e-3, "pred_masks")
+        close(inst.mask_scores[pg], r["mask_scores"], 1e-3, "mask_scores")
         assert inst.pred_classes.dtype == torch.int64 and tuple(inst.pred_masks.shape[1:]) == (1, 28, 28)
     t = model.forward_tensor(x[:1], hw=[(800, 1280)])
     assert [tuple(v.shape[1:]) for v in t] == [(2,), (), (4,), (), (1, 28, 28), ()]
