@@ -108,6 +108,20 @@ def roofline_leg(model, x, sizes):
         else:
             roof["mfma_busy"] = round(e["mfma_busy_frac"], 4)
             roof["mfma_busy_source"] = "profiles/{}_{} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE; busy cycles / (4 SIMDs x busy CU cycles))".format(PROFILE_ROUND, fname)
+    # the same kernel's average duration in the rocprofv3 --kernel-trace --stats run kept under profiles/ (quoted while that run was of
+    # these kernel sources): the event pair above also times the eager launch (~10 us), the kernel trace does not
+    try:
+        import csv
+        under = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_bench_under_rocprof.json")))
+        if under.get("roofline", {}).get("kernel_source_hash") == khash:
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_bench_kernel_stats.csv"))):
+                if dom + "(" in row["Name"]:
+                    us = float(row["AverageNs"]) / 1e3
+                    roof["avg_launch_us_rocprof"] = round(us, 2)
+                    roof["frac_rocprof"] = round(d["exec"] / d["launches"] / (us * 1e-6) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4)
+                    break
+    except Exception:
+        pass
     return roof
 
 
