@@ -10,11 +10,16 @@
 //   a wave-uniform scalar base) — 0.75 operand registers per MFMA where the 32 px x 128 couts wave tile of conv_igemm took 1.25, and half
 //   its global->LDS staging bytes.  The activations are staged global -> registers -> LDS once per workgroup and 16-channel chunk with
 //   raw buffer loads (rows past the last pixel come back as zeros from the hardware range check: no selects), double-buffered, one
-//   barrier per chunk = per 64 (MT = 4) MFMAs of a wave.
+//   barrier per chunk = per 64 (MT = 4) MFMAs of a wave, placed BETWEEN the two halves of a chunk with the LDS operand reads half a
+//   chunk ahead of their MFMAs (see "pipeline" below).
 //   The weights are the layout conv_igemm already packs ([chunk][cout_pad][16 channels]); K order and accumulation order are the
 //   same as conv_igemm's, so the two kernels agree bit for bit.
+//   Everything outside the MFMAs is priced in VALU instructions: fp32 MFMA and VALU do not co-execute, and a VALU instruction issued
+//   next to the other workgroup's MFMA stream waits for a gap in it — the epilogue is 1.5 VALU per stored value (see there).
+//   POOL variant: the per-cout sums of the stored values over the wave's rows (the eSE average pool, vovnet.py:255-256) leave with the
+//   epilogue — a lane is a cout, so it is one packed add per two values and no pass over the map.
 //
-// Reference call sites replaced: the OSA concat 1x1 convs (vovnet.py:222-236), FPN laterals, the mask head's deconv as a 1x1.
+// Reference call sites replaced: the OSA concat 1x1 convs (vovnet.py:222-236), an FPN lateral, the mask head's deconv as a 1x1.
 #include <math.h>
 
 #include <type_traits>

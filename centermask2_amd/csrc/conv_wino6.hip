@@ -20,13 +20,16 @@
 //       pass 2 (by the MFMA waves, in registers, right in front of the MFMAs): a lane reads the 5 W values of its tile that one half of
 //         a frequency row needs (conflict-free image, see w6_slot) and forms 3 frequencies with 6 FMAs per channel.
 //     So the 36-plane V image (74 KiB per 16 channels — it would not fit twice beside a second workgroup) never exists, LDS traffic per
-//     MFMA is a fraction of the 2x2 kernel's, the transform costs ~3 VALU instructions per MFMA, and ONE barrier per chunk (36 MFMAs
-//     per wave) is enough — it never waits for memory.
+//     MFMA is a fraction of the 2x2 kernel's, and ONE barrier per chunk (36 MFMAs per wave) is enough — it never waits for memory.
+//   * VALU instructions are the currency: fp32 MFMA and VALU do not co-execute here and a period costs 2 waves x (36 MFMAs x 64 +
+//     N_valu x ~8) cycles.  A wave issues 60 packed transform instructions + 4 others per period (hand-written v_pk_* blocks, row-B sample
+//     addresses set up once, two periods per trip so that the W buffer is a compile-time offset); the fused-affine variant adds 48.
 //   * weights never touch LDS: U is packed so that every operand load of a wave is one contiguous KiB ([chunk][cout tile][wave][9][lane][4])
 //     and is fetched two steps (24 MFMAs) ahead into registers, as in the 2x2 kernel.
 //   * epilogue: each wave reduces its frequencies along b in registers (6 -> 4 and 3 -> 4 partial values per entry), the four waves swap
 //     those through LDS in two rounds, and wave w finishes the 8 tiles of accumulator registers 4w..4w+3: column pass, scale/shift/ReLU,
-//     NHWC stores, GroupNorm statistics.
+//     NHWC stores, GroupNorm statistics — on pairs of accumulator registers with packed fp32, interior tiles stored through a scalar-walked
+//     base + one lane offset per tile (~460 VALU instructions per wave; the scalar form took ~1080 and 12.4 us beside a partner's MFMAs).
 //
 // Reference call sites replaced: the same 3x3 stride-1 convs as the 2x2 kernel (vovnet.py:205-219, d2 FPN outputs, fcos.py:169-200,
 // sam.py:58-70, maskiou_head.py:81-88).
