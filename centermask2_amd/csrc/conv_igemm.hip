@@ -910,6 +910,22 @@ static int pointwise_mt(const cmk_conv_desc* d, int n) {
     return wg2 >= 256 ? (wg4 >= 1024 ? 4 : 2) : 0;
 }
 
+// The same for the gather form of a 3x3 conv on that kernel (tune_wm 9, or the untuned default for stride-2 convs of at least 1024
+// 256-pixel workgroups: stem_3).
+static int gather_mt(const cmk_conv_desc* d, int n) {
+    const int cout32 = (d->Cout + 31) / 32;
+    const long in_pix = (long)d->N * d->H * d->W;
+    const long out_pix = (long)d->N * (d->stride == 1 ? d->H : (d->H - 1) / 2 + 1) * (d->stride == 1 ? d->W : (d->W - 1) / 2 + 1);
+    if (d->ksize != 3 || n != 1 || (cout32 != 4 && cout32 <= 7) || (d->Cin & 31) || d->in_scale || d->in_relu || d->res_mode == 2 || d->splitk > 1 ||
+        d->gn_ws || d->pool_ws || in_pix * d->x_cs * 4 >= (1L << 31) || d->H >= 32768 || d->W >= 32768)
+        return 0;
+    if (d->tune_wm == 9) return (d->tune_wn == 4 || d->tune_wn == 2) ? d->tune_wn : 0;
+    if (d->tune_wm || d->tune_sc || d->tune_wn || d->stride != 2) return 0;
+    const long ctiles = cdiv(cout32, 4);
+    const long wg4 = ((out_pix + 255) / 256) * ctiles;
+    return wg4 >= 1024 ? 4 : 0;          // measured (tools/bench_ga.py): stem_3 1.28x conv_igemm; the 14 -> 7 maskiou conv and P6/P7 stay on its split-K gather form
+}
+
 static int run(const cmk_conv_desc* descs, int n, void* stream) {
     const cmk_conv_desc* d = &descs[0];
     ConvArgs a;
@@ -958,6 +974,13 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         a.cout_pad = cdiv(cout32, 4) * 128;
         a.gn_ws = d->gn_ws;
         return launch_pw(a, d->tune_wn, st);
+    }
+    if (d->tune_wm == 9) {                             // gather form of a 3x3 conv on the pointwise GEMM kernel; tune_wn = accumulator rows per wave
+        const int mt = gather_mt(d, n);
+        if (!mt) return fail(CMK_EINVAL, "conv: pointwise gather variant not available for this conv%s", "");
+        a.cout_pad = cdiv(cout32, 4) * 128;
+        a.ga_stride = d->stride;
+        return launch_pw(a, mt, st);
     }
     if (d->tune_wm == 7) {                             // gather form: 3x3 (stride 1|2) as a flattened-pixel GEMM over 9x the K chunks
         if (d->ksize != 3 || n != 1 || d->res_mode == 2 || d->in_scale || (d->tune_wn != 1 && d->tune_wn != 2 && d->tune_wn != 4))
@@ -1024,6 +1047,11 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         }
         if (const int mt = pointwise_mt(d, n)) {
             a.cout_pad = cdiv(cout32, 4) * 128;
+            return launch_pw(a, mt, st);
+        }
+        if (const int mt = gather_mt(d, n)) {
+            a.cout_pad = cdiv(cout32, 4) * 128;
+            a.ga_stride = d->stride;
             return launch_pw(a, mt, st);
         }
         v = choose_variant(a, taps, d->stride, cout32);

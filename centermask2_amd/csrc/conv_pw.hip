@@ -32,7 +32,12 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 pw_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
 // POOL: also leave the per-block sums of the stored values in a.pool_ws (the eSE average pool of the aggregation conv, cmk.h)
-template <int MT, bool POOL>
+// GA ("gather"): a 3x3 conv (stride a.ga_stride = 1 | 2, padding 1) as the same GEMM over flattened OUTPUT pixels whose K walks 9 taps x Cin/16
+// chunks: the staged row of a thread is gathered per tap straight from the image (an offset outside the resource where the tap falls
+// outside it: zeros).  No halo reuse — each input pixel is read 9/stride^2 times from L2 — so it is for the convs Winograd does not take:
+// stride 2 with enough pixels to fill the chip (stem_3 vovnet.py:412: 1.28x conv_igemm; the small stride-2 convs stay on its split-K
+// gather form).  Weights: conv_igemm's [tap][chunk][cout_pad][16]; same tap-major K order as its gather form (bit-identical to it).
+template <int MT, bool POOL, bool GA>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     constexpr int BM = 64 * MT;         // pixels per workgroup
     constexpr int ABUF = BM * PST;      // floats per LDS buffer (rows of 16 channels, pitch 20)
@@ -52,7 +57,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     const long total_pix = P.total_pix;
     const long pix0 = (long)bx * BM;
     const int co0 = by * 128 + wn * 64;
-    const int nchunks = a.Cin >> 4;     // even (host)
+    const int cin_chunks = a.Cin >> 4;
+    const int nchunks = GA ? 9 * cin_chunks : cin_chunks;     // even (host)
 
     // ---- activations: global -> registers -> LDS ------------------------------------------------------------------------------------
     // thread = (row tid>>2 (+64 per iteration), channel quad tid&3); a row past the last pixel gets an offset outside the resource
@@ -61,20 +67,50 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
         const unsigned long long base = (unsigned long long)P.x;
         rsrc.x = __builtin_amdgcn_readfirstlane((int)(base & 0xffffffffull));
         rsrc.y = __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffull));
-        rsrc.z = __builtin_amdgcn_readfirstlane((int)(total_pix * a.x_cs * 4));      // < 2^31 (host)
+        rsrc.z = __builtin_amdgcn_readfirstlane((int)((GA ? (long)P.N * P.H * P.W : total_pix) * a.x_cs * 4));      // < 2^31 (host)
         rsrc.w = 0x00020000;
     }
     int a_voff[MT];
+    int ga_base[GA ? MT : 1], ga_hw[GA ? MT : 1];       // GA: byte offset of the window's top-left sample (may be negative), (ih0 << 16) | (iw0 & 0xffff)
 #pragma unroll
     for (int it = 0; it < MT; ++it) {
         const long px = pix0 + it * 64 + (tid >> 2);
-        a_voff[it] = px < total_pix ? (int)((px * a.x_cs + a.x_co + (tid & 3) * 4) * 4) : (int)0x80000000;
+        if (GA) {
+            const bool pv = px < total_pix;
+            const long pp = pv ? px : 0;
+            const long hw = (long)P.Ho * P.Wo;
+            const int n_ = (int)(pp / hw);
+            const int rem = (int)(pp - (long)n_ * hw);
+            const int oh = rem / P.Wo, ow = rem - oh * P.Wo;
+            const int ih0 = pv ? oh * a.ga_stride - 1 : -4, iw0 = ow * a.ga_stride - 1;      // -4: every tap lands outside
+            ga_base[it] = (((n_ * P.H + ih0) * P.W + iw0) * a.x_cs + a.x_co + (tid & 3) * 4) * 4;
+            ga_hw[it] = (ih0 << 16) | (iw0 & 0xffff);
+            a_voff[it] = (int)0x80000000;
+        } else {
+            a_voff[it] = px < total_pix ? (int)((px * a.x_cs + a.x_co + (tid & 3) * 4) * 4) : (int)0x80000000;
+        }
     }
     const int a_dst = (tid >> 2) * PST + (tid & 3) * 4;
     f32x4 a_st[MT];
+    int ga_tap = -1;                    // GA: the tap a_voff[] is set up for (the requests walk the chunks in order)
     auto load_A = [&](int chunk) {
+        int soff = chunk * 64;
+        if (GA) {
+            const int tap = chunk / cin_chunks;             // wave-uniform
+            soff = (chunk - tap * cin_chunks) * 64;
+            if (tap != ga_tap) {
+                ga_tap = tap;
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const int delta = (kh * P.W + kw) * a.x_cs * 4;
 #pragma unroll
-        for (int it = 0; it < MT; ++it) a_st[it] = pw_buffer_load(rsrc, a_voff[it], chunk * 64, 0);
+                for (int it = 0; it < MT; ++it) {
+                    const int ih = (ga_hw[it] >> 16) + kh, iw = (int)(short)(ga_hw[it] & 0xffff) + kw;
+                    a_voff[it] = (ih >= 0 && ih < P.H && iw >= 0 && iw < P.W) ? ga_base[it] + delta : (int)0x80000000;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MT; ++it) a_st[it] = pw_buffer_load(rsrc, a_voff[it], soff, 0);
     };
     auto store_A = [&](int buf) {
         float* dst = smem + buf * ABUF + a_dst;
@@ -324,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int MT, bool POOL>
+template <int MT, bool POOL, bool GA>
 static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * MT;
 #ifdef PW_TRACE
@@ -334,7 +370,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int LDS_BYTES = 2 * BM * PST * 4 + 4 * 64 * 8 + PW_LDS_EXTRA;      // PW_LDS_EXTRA: experiments with one workgroup per CU
     static DeviceOnce once;
     int rc0 = once.run([]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT, POOL, GA>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_pw: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     });
     if (rc0) return rc0;
@@ -347,21 +383,29 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     const long tiles = (p.total_pix + BM - 1) / BM;
     a.total_tiles = (int)tiles;
     a.grid_y = a.cout_pad / 128;
-    hipLaunchKernelGGL((conv_pw_kernel<MT, POOL>), dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y)), dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_pw_kernel<MT, POOL, GA>), dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y)), dim3(256), LDS_BYTES, st, a);
     return check_launch("conv_pw");
 }
 
-// mt = 4 | 2.  The caller (conv_igemm.hip: run) has filled the problem, views, epilogue options and cout_pad.
+// mt = 4 | 2.  The caller (conv_igemm.hip: run) has filled the problem, views, epilogue options and cout_pad; a.ga_stride = 1 | 2 asks for
+// the gather form of a 3x3 conv (a.w then is conv_igemm's 9-tap packing), 0 for a 1x1 conv.
 int launch_pw(ConvArgs& a, int mt, hipStream_t st) {
     const ConvProblem& p = a.p[0];
     if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws || a.ksplit > 1 || a.res_mode == 2)
         return fail(CMK_EINVAL, "conv_pw: one problem, no input affine / input ReLU / GroupNorm statistics / split-K / upsampled residual%s", "");
-    if ((a.Cin & 31) || (a.cout_pad & 127)) return fail(CMK_EINVAL, "conv_pw: needs Cin %% 32 == 0 and Cout > 224%s", "");
-    if (p.total_pix * a.x_cs * 4 >= (1L << 31)) return fail(CMK_EINVAL, "conv_pw: input view of 2 GiB or more%s", "");
+    if ((a.Cin & 31) || (a.cout_pad & 127)) return fail(CMK_EINVAL, "conv_pw: needs Cin %% 32 == 0 and Cout in 97..128 or > 224%s", "");
+    const long in_pix = a.ga_stride ? (long)p.N * p.H * p.W : p.total_pix;
+    if (in_pix * a.x_cs * 4 >= (1L << 31)) return fail(CMK_EINVAL, "conv_pw: input view of 2 GiB or more%s", "");
     if ((long)(64 * 4 + 8) * a.y_cs >= (1L << 30) || (long)(64 * 4 + 8) * a.res_cs >= (1L << 30)) return fail(CMK_EINVAL, "conv_pw: output row too wide%s", "");
+    if (a.ga_stride) {
+        if (a.pool_ws || p.H >= 32768 || p.W >= 32768) return fail(CMK_EINVAL, "conv_pw: gather form: no pooled sums, maps below 32768 x 32768%s", "");
+        if (mt == 4) return launch_pw_mt<4, false, true>(a, st);
+        if (mt == 2) return launch_pw_mt<2, false, true>(a, st);
+        return fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
+    }
     if (a.pool_ws && (long)p.Ho * p.Wo < 32 * mt) return fail(CMK_EINVAL, "conv_pw: pooled sums need H*W >= the block of %s%ld rows", "", 32 * mt);
-    if (mt == 4) return a.pool_ws ? launch_pw_mt<4, true>(a, st) : launch_pw_mt<4, false>(a, st);
-    if (mt == 2) return a.pool_ws ? launch_pw_mt<2, true>(a, st) : launch_pw_mt<2, false>(a, st);
+    if (mt == 4) return a.pool_ws ? launch_pw_mt<4, true, false>(a, st) : launch_pw_mt<4, false, false>(a, st);
+    if (mt == 2) return a.pool_ws ? launch_pw_mt<2, true, false>(a, st) : launch_pw_mt<2, false, false>(a, st);
     return fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
 }
 

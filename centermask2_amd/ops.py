@@ -234,7 +234,7 @@ def _variant_on_menu(tv) -> bool:
     """(wm, sc, wn[, splitk]) names a kernel this library has (older tables may carry variants that were removed since)."""
     wm, sc, wn = tv[:3]
     sk = tv[3] if len(tv) > 3 else 1
-    return (wm in (1, 2, 5, 6, 7, 8) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
+    return (wm in (1, 2, 5, 6, 7, 8, 9) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
 
 
 def load_tuned(path: str) -> int:
@@ -290,6 +290,8 @@ def _tune(descs, n, key) -> None:
     cands = [(wm, sc, wn, sk) for wn in range(1, 8) for wm in (1, 2) for sc in (16, 32) for sk in sks]
     if small and d0.ksize == 3:
         cands += [(7, 32, wn, sk) for wn in (1, 2, 4) for sk in sks]      # gather form
+    if d0.ksize == 3:
+        cands += [(9, 32, 4, 1), (9, 32, 2, 1)]   # gather form of a 3x3 conv on the pointwise GEMM kernel (conv_pw.hip GA); same K order as the direct kernels
     if d0.ksize == 1:
         cands += [(8, 32, 4, 1), (8, 32, 2, 1)]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
     if ALLOW_WINOGRAD:
@@ -760,8 +762,8 @@ def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) 
         wgs = sum(cd(n, 2) for n, h, w in shapes) if wn == 2 else sum(n * cd(h, 12) * cd(w, 40) for n, h, w in shapes)
         return float(wgs * cd(cout, 32) * (cin_pad // 8) * 144 * 4096)
     cout_pad = _lib.load().cmk_conv_cout_pad(cout)
-    if wm == 8:      # workgroup = 64*wn pixels x 128 couts
-        return float(sum(cd(n * h * w, 64 * wn) for n, h, w in shapes)) * (64 * wn) * cout_pad * cin_pad * 2.0
+    if wm in (8, 9):      # workgroup = 64*wn pixels x 128 couts; 9 = the gather form (K = 9 taps x Cin)
+        return float(sum(cd(n * h * w, 64 * wn) for n, h, w in shapes)) * (64 * wn) * (cd(cout, 128) * 128) * cin_pad * taps * 2.0
     if wm not in (1, 2):                      # cost-model / gather / split-K variants: geometry of the smallest tile
         wm, sc = 1, (32 if taps == 1 else 16)
     if taps == 9 and tuple(tv[:1]) != (7,):
@@ -784,7 +786,9 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False) -> str:
         return "conv_wino6_kernel<{}, {}>".format("true" if aff else "false", 1 if tv[2] == 2 else 0)
     wm, sc, wn = tv[:3]
     if wm == 8:
-        return "conv_pw_kernel<{}, {}>".format(wn, "true" if pool else "false")
+        return "conv_pw_kernel<{}, {}, false>".format(wn, "true" if pool else "false")
+    if wm == 9:
+        return "conv_pw_kernel<{}, false, true>".format(wn)
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)
     return "conv_igemm_kernel<{}, {}, {}, {}, {}, false>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)

@@ -312,6 +312,25 @@ def test_conv_pointwise_pooled_sums_and_ese_gate(dev, cmk_lib, case):
     assert cmk_lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
 
 
+@pytest.mark.parametrize("mt", [4, 2])
+@pytest.mark.parametrize("case", [(1, 21, 35, 64, 128, 2), (2, 14, 14, 256, 256, 2), (1, 17, 23, 32, 128, 1), (3, 9, 11, 64, 320, 2), (1, 40, 64, 64, 128, 2)])
+def test_conv_pointwise_gather_form(dev, case, mt):
+    """tune_wm 9: a 3x3 conv (stride 1 | 2) as the pointwise kernel's GEMM over 9 taps x Cin/16 chunks, rows gathered per tap with
+    bounds-checked loads — odd sizes (every border case of the padding), ragged pixel counts, Cout that is not a multiple of 128.  Same K
+    order (tap-major) as conv_igemm's gather form: bit-identical to it."""
+    n, h, w, cin, cout, stride = case
+    x = _rand((n, cin, h, w), 91)
+    wt = _rand((cout, cin, 3, 3), 92, (2.0 / (9 * cin)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(93)) + 0.5
+    shift = _rand((cout,), 94, 0.1)
+    ref = F.relu(F.conv2d(x, wt, None, stride=stride, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    rc, y = _run_variant(dev, x, wt, scale, shift, (9, 32, mt), stride=stride)
+    assert rc == 0
+    _close(y.nchw(), ref)
+    rc0, y0 = _run_variant(dev, x, wt, scale, shift, (7, 32, 1), stride=stride)
+    assert rc0 == 0 and torch.equal(y.t, y0.t)
+
+
 WINO6_CASES = [(2, 37, 45, 64, 128), (1, 16, 16, 256, 256), (1, 25, 40, 224, 224), (2, 14, 14, 256, 80), (1, 100, 160, 32, 5),
                (1, 12, 40, 128, 32), (1, 13, 41, 48, 33), (3, 5, 3, 32, 64), (1, 50, 80, 192, 192)]
 
