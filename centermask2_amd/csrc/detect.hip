@@ -206,12 +206,75 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float* __restrict__ 
     __syncthreads();
 
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // The greedy scan below stops after `topk` survivors, so it only ever consumes a prefix of the descending-score order.  With many
+    // candidates (the fork applies no pre-NMS top-k, fcos_outputs.py:444-449) sorting all of them is most of this kernel: attempt 0
+    // sorts only the candidates whose key's top 12 bits are below the bin where the running count first reaches NEED — a superset of
+    // the NEED best, compacted IN ORDER so that the radix sort stays stable on the candidate index — and attempt 1 (everything) runs
+    // only if that prefix is exhausted before `topk` boxes are kept.
+    const int NEED = max(2048, 16 * topk);
+    int sorted_cnt = cnt;
+    for (int attempt = (cnt > 2 * NEED ? 0 : 1); attempt < 2; ++attempt) {
     uint32_t *kin = k0, *vin = v0, *kout = k1, *vout = v1;
+    sorted_cnt = cnt;
+    if (attempt == 1 && cnt > 2 * NEED) {          // the subset pass overwrote (k0, v0)
+        for (int i = tid; i < cnt; i += NT) { k0[i] = ~__float_as_uint(score[i]); v0[i] = (uint32_t)i; }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (attempt == 0) {
+        int* hist12 = &wcnt[0][0];                  // 4096 bins over the key's top 12 bits
+        for (int j = tid; j < 4096; j += NT) hist12[j] = 0;
+        __syncthreads();
+        for (int i = tid; i < cnt; i += NT) atomicAdd(&hist12[k0[i] >> 20], 1);
+        __syncthreads();
+        // thread t owns bins 4t..4t+3; block-wide exclusive prefix of the per-thread sums
+        const int h0 = hist12[4 * tid], h1 = hist12[4 * tid + 1], h2 = hist12[4 * tid + 2], h3 = hist12[4 * tid + 3];
+        const int mine = h0 + h1 + h2 + h3;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) base[wave] = incl;
+        __syncthreads();
+        int pre = incl - mine;
+        for (int w = 0; w < wave; ++w) pre += base[w];
+        if (pre < NEED && pre + mine >= NEED) {     // exactly one thread: the bin where the count reaches NEED
+            int c = pre + h0, d = 4 * tid;
+            if (c < NEED) { c += h1; ++d; }
+            if (c < NEED) { c += h2; ++d; }
+            if (c < NEED) { c += h3; ++d; }
+            hist[0] = d;
+            hist[1] = c;
+        }
+        __syncthreads();
+        const uint32_t dmax = (uint32_t)hist[0];
+        sorted_cnt = hist[1];
+        __syncthreads();
+        // ordered compaction of the candidates of bins <= dmax into (k1, v1)
+        int run = 0;
+        for (int t0 = 0; t0 < cnt; t0 += NT) {
+            const int i = t0 + tid;
+            const bool take = i < cnt && (k0[i] >> 20) <= dmax;
+            const unsigned long long bm = __ballot(take);
+            if (lane == 0) base[wave] = __popcll(bm);
+            __syncthreads();
+            int pos = run + __popcll(bm & lt);
+            for (int w = 0; w < wave; ++w) pos += base[w];
+            if (take) { k1[pos] = k0[i]; v1[pos] = (uint32_t)i; }
+            int tot = 0;
+            for (int w = 0; w < NW; ++w) tot += base[w];
+            run += tot;
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        kin = k1; vin = v1; kout = k0; vout = v0;
+    }
+    const int scnt = sorted_cnt;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = pass * 8;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (int i = tid; i < cnt; i += NT) atomicAdd(&hist[(kin[i] >> shift) & 255], 1);
+        for (int i = tid; i < scnt; i += NT) atomicAdd(&hist[(kin[i] >> shift) & 255], 1);
         __syncthreads();
         if (tid == 0) {
             int run = 0;
@@ -220,11 +283,11 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float* __restrict__ 
         __syncthreads();
         const bool trivial = false;
         (void)trivial;
-        for (int t0 = 0; t0 < cnt; t0 += NT) {
+        for (int t0 = 0; t0 < scnt; t0 += NT) {
             for (int j = tid; j < NW * 256; j += NT) (&wcnt[0][0])[j] = 0;
             __syncthreads();
             const int i = t0 + tid;
-            const bool valid = i < cnt;
+            const bool valid = i < scnt;
             uint32_t key = valid ? kin[i] : 0u, val = valid ? vin[i] : 0u;
             int digit = valid ? (int)((key >> shift) & 255) : 256;
             // lanes of this wave with the same digit
@@ -257,7 +320,7 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float* __restrict__ 
         __threadfence_block();
         __syncthreads();
     }
-    // after 4 passes the sorted order is back in (k0, v0)
+    // after 4 passes the sorted order is back in the buffer the passes started from
     const uint32_t* order = vin;
 
     // greedy suppression by the first wave; stop once topk boxes are kept
@@ -265,9 +328,9 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float* __restrict__ 
         const bool per_class = cnt >= 40000;                 // detectron2 batched_nms switches strategy there
         const float off_unit = per_class ? 0.0f : (s_maxc + 1.0f);
         int nkept = 0;
-        for (int c0 = 0; c0 < cnt && nkept < topk; c0 += 64) {
+        for (int c0 = 0; c0 < scnt && nkept < topk; c0 += 64) {
             const int pos = c0 + lane;
-            bool alive = pos < cnt;
+            bool alive = pos < scnt;
             int idx = alive ? (int)order[pos] : 0;
             float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
             int mycls = -1;
@@ -312,6 +375,10 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float* __restrict__ 
             out_count[n] = nkept;
             s_nkept = nkept;
         }
+    }
+    __syncthreads();
+    if (s_nkept >= topk || sorted_cnt >= cnt) break;      // enough survivors, or everything was sorted
+    __syncthreads();
     }
     __syncthreads();
     // zero the unused tail so padded consumers read finite values

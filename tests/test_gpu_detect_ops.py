@@ -153,6 +153,29 @@ def test_nms_per_class_branch_over_40000(dev):
     assert torch.equal(det["idx"][0, :int(det["counts"][0])].cpu().long(), keep)
 
 
+def test_nms_prefix_sort_falls_back_to_the_full_sort(dev):
+    """More than 2 x NEED candidates: the kernel first sorts only a prefix of the score order (the bins holding the ~2048 best).  Here the
+    6000 best-scoring candidates are one and the same box, so that prefix yields a single survivor and the kernel has to redo the job
+    on all candidates; the result must still be detectron2's batched_nms."""
+    m, cap = 12000, 16384
+    g = torch.Generator().manual_seed(21)
+    i = torch.arange(m)
+    box = torch.stack([(i % 150) * 12.0, (i // 150) * 12.0, (i % 150) * 12.0 + 8, (i // 150) * 12.0 + 8], 1)
+    score = torch.rand((m,), generator=g) * 0.4
+    box[:6000] = torch.tensor([3000.0, 3000.0, 3100.0, 3100.0])
+    score[:6000] = 0.5 + torch.rand((6000,), generator=g) * 0.4
+    cls = torch.zeros((m,), dtype=torch.long)
+    cand = dict(box=torch.zeros((1, cap, 4)), score=torch.zeros((1, cap)), cls=torch.zeros((1, cap), dtype=torch.int32),
+                loc=torch.zeros((1, cap, 2)), counts=torch.tensor([m], dtype=torch.int32))
+    cand["box"][0, :m], cand["score"][0, :m] = box, score
+    cand = {k: v.to(dev) for k, v in cand.items()}
+    det = ops.nms_topk(cand, 0.6, 50)
+    torch.cuda.synchronize()
+    keep = O.batched_nms(box, score, cls, 0.6)[:50]
+    assert int(det["counts"][0]) == 50
+    assert torch.equal(det["idx"][0].cpu().long(), keep)
+
+
 def test_sort_is_stable_descending_full_order(dev):
     """topk=64 on non-overlapping boxes returns the 64 best by (score desc, index asc): checks the radix sort."""
     m, cap = 20000, 32768
