@@ -900,9 +900,10 @@ static int setup_gn(ConvArgs& a, const cmk_conv_desc* d) {
 static int pointwise_mt(const cmk_conv_desc* d, int n) {
     const int cout32 = (d->Cout + 31) / 32;
     const long total_pix = (long)d->N * d->H * d->W;
-    if (d->ksize != 1 || n != 1 || cout32 <= 7 || (d->Cin & 31) || d->in_scale || d->in_relu || d->res_mode == 2 || d->splitk > 1 || d->gn_ws ||
+    if (d->ksize != 1 || n != 1 || cout32 <= 7 || (d->Cin & 31) || d->in_scale || d->in_relu || d->splitk > 1 || d->gn_ws ||
         total_pix * d->x_cs * 4 >= (1L << 31))
         return 0;
+    if (d->res_mode == 2 && ((d->W & 1) || d->pool_ws || (long)d->N * d->Hr * d->Wr * d->res_cs * 4 >= (1L << 31))) return 0;     // FPN top-down add: even widths
     if (d->tune_wm == 8) return (d->tune_wn == 4 || d->tune_wn == 2) ? d->tune_wn : 0;
     if (d->tune_wm || d->tune_sc || d->tune_wn) return 0;
     const long ctiles = cdiv(cout32, 4);

@@ -37,7 +37,9 @@ __device__ f32x4 pw_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) _
 // outside it: zeros).  No halo reuse — each input pixel is read 9/stride^2 times from L2 — so it is for the convs Winograd does not take:
 // stride 2 with enough pixels to fill the chip (stem_3 vovnet.py:412: 1.28x conv_igemm; the small stride-2 convs stay on its split-K
 // gather form).  Weights: conv_igemm's [tap][chunk][cout_pad][16]; same tap-major K order as its gather form (bit-identical to it).
-template <int MT, bool POOL, bool GA>
+// UPRES: the FPN top-down add — the residual is the nearest-neighbour 2x upsampling of a map of half the size (a.res, a.Hr x a.Wr); needs an
+// even output width (then the pixel pairs the epilogue handles share one residual pixel).
+template <int MT, bool POOL, bool GA, bool UPRES>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     constexpr int BM = 64 * MT;         // pixels per workgroup
     constexpr int ABUF = BM * PST;      // floats per LDS buffer (rows of 16 channels, pitch 20)
@@ -255,7 +257,20 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     const long wpix0 = pix0 + wm * (MT * 32);
     float* ybase = P.y + wpix0 * a.y_cs;                                   // wave-uniform; rows are added to the lane offset below
     const float* rbase = a.res_mode == 1 ? a.res + wpix0 * a.res_cs : nullptr;
-    const bool interior = a.res_mode == 0 && pix0 + BM <= total_pix && co0 + 64 <= a.Cout;
+    const bool interior = (UPRES || a.res_mode == 0) && pix0 + BM <= total_pix && co0 + 64 <= a.Cout;
+    if (UPRES) {
+        // byte offset of every row's residual pixel, once per workgroup, into the (now free) LDS: the epilogue then needs no address arithmetic
+        // beyond one add per pixel pair
+        if (tid < BM) {
+            const long p = min(pix0 + tid, total_pix - 1);
+            const long hw = (long)P.Ho * P.Wo;
+            const int n_ = (int)(p / hw);
+            const int rem = (int)(p - (long)n_ * hw);
+            const int oh = rem / P.Wo, ow = rem - oh * P.Wo;
+            reinterpret_cast<int*>(smem)[tid] = (int)(((((long)n_ * a.Hr + (oh >> 1)) * a.Wr + (ow >> 1)) * a.res_cs + a.res_co) * 4);
+        }
+        __syncthreads();
+    }
     // POOL: this wave's 32*MT rows are block g of the flattened pixels; rows from `bnd` on belong to the next image
     const long blk_g = (long)bx * 2 + wm;
     int bnd = MT * 32;
@@ -289,11 +304,27 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
                 unsigned long long rowp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(yb >> 32)) << 32) |
                                           (unsigned)__builtin_amdgcn_readfirstlane((int)yb);
                 const unsigned long long row1 = (unsigned long long)a.y_cs * 4u, row5 = row1 * 5u;
+                float rv[UPRES ? MT : 1][8];
+                if constexpr (UPRES) {
+                    // one residual value per pixel pair (rows r, r+1 with r even: the same coarse pixel), all 8*MT of them requested before the
+                    // first store of this cout tile and waited for ONCE: a wait in front of each use would also wait for the stores in between
+                    const int* tab = reinterpret_cast<const int*>(smem) + wm * (MT * 32) + 4 * hh;
+                    const char* rb = reinterpret_cast<const char*>(a.res);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            rv[m][j] = *reinterpret_cast<const float*>(rb + (unsigned)(tab[m * 32 + ((2 * j) & 3) + 8 * (j >> 1)] + co * 4));
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        asm volatile("" : "+v"(rv[m][0]), "+v"(rv[m][1]), "+v"(rv[m][2]), "+v"(rv[m][3]), "+v"(rv[m][4]), "+v"(rv[m][5]), "+v"(rv[m][6]), "+v"(rv[m][7]));
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         f32x2 v = __builtin_elementwise_fma(f32x2{acc[m][nn][r], acc[m][nn][r + 1]}, sc2, sh2);
+                        if constexpr (UPRES) v += f32x2{rv[m][r >> 1], rv[m][r >> 1]};
                         const float v0 = fmaxf(v.x, lo), v1 = fmaxf(v.y, lo);
                         if (POOL) pool2 += f32x2{v0, v1};
                         // ("+s": the pointer is walked between the stores, not computed 128 times up front and spilled)
@@ -330,6 +361,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
                         const int step = (r & 3) == 3 ? 5 : 1;
                         if (m * 32 + (r & 3) + 8 * (r >> 2) < rows_left) {
                             if (a.res_mode == 1) v += rbase[roff];
+                            if (UPRES)
+                                v += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.res) +
+                                     (unsigned)(reinterpret_cast<const int*>(smem)[wm * (MT * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] + co * 4));
                             v = fmaxf(v, lo);
                             ybase[off] = v;
                             if (POOL) { if (m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < bnd) poolA += v; else poolB += v; }
@@ -360,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int MT, bool POOL, bool GA>
+template <int MT, bool POOL, bool GA, bool UPRES = false>
 static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * MT;
 #ifdef PW_TRACE
@@ -370,7 +404,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int LDS_BYTES = 2 * BM * PST * 4 + 4 * 64 * 8 + PW_LDS_EXTRA;      // PW_LDS_EXTRA: experiments with one workgroup per CU
     static DeviceOnce once;
     int rc0 = once.run([]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT, POOL, GA>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT, POOL, GA, UPRES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_pw: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     });
     if (rc0) return rc0;
@@ -383,7 +417,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     const long tiles = (p.total_pix + BM - 1) / BM;
     a.total_tiles = (int)tiles;
     a.grid_y = a.cout_pad / 128;
-    hipLaunchKernelGGL((conv_pw_kernel<MT, POOL, GA>), dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y)), dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_pw_kernel<MT, POOL, GA, UPRES>), dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y)), dim3(256), LDS_BYTES, st, a);
     return check_launch("conv_pw");
 }
 
@@ -391,8 +425,12 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
 // the gather form of a 3x3 conv (a.w then is conv_igemm's 9-tap packing), 0 for a 1x1 conv.
 int launch_pw(ConvArgs& a, int mt, hipStream_t st) {
     const ConvProblem& p = a.p[0];
-    if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws || a.ksplit > 1 || a.res_mode == 2)
-        return fail(CMK_EINVAL, "conv_pw: one problem, no input affine / input ReLU / GroupNorm statistics / split-K / upsampled residual%s", "");
+    if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws || a.ksplit > 1)
+        return fail(CMK_EINVAL, "conv_pw: one problem, no input affine / input ReLU / GroupNorm statistics / split-K%s", "");
+    if (a.res_mode == 2) {          // FPN top-down add
+        if (a.ga_stride || a.pool_ws || (p.Wo & 1) || (long)p.N * a.Hr * a.Wr * a.res_cs * 4 >= (1L << 31))
+            return fail(CMK_EINVAL, "conv_pw: the upsampled residual needs a 1x1 conv, an even output width, no pooled sums, a residual below 2 GiB%s", "");
+    }
     if ((a.Cin & 31) || (a.cout_pad & 127)) return fail(CMK_EINVAL, "conv_pw: needs Cin %% 32 == 0 and Cout in 97..128 or > 224%s", "");
     const long in_pix = a.ga_stride ? (long)p.N * p.H * p.W : p.total_pix;
     if (in_pix * a.x_cs * 4 >= (1L << 31)) return fail(CMK_EINVAL, "conv_pw: input view of 2 GiB or more%s", "");
@@ -404,6 +442,11 @@ int launch_pw(ConvArgs& a, int mt, hipStream_t st) {
         return fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
     }
     if (a.pool_ws && (long)p.Ho * p.Wo < 32 * mt) return fail(CMK_EINVAL, "conv_pw: pooled sums need H*W >= the block of %s%ld rows", "", 32 * mt);
+    if (a.res_mode == 2) {
+        if (mt == 4) return launch_pw_mt<4, false, false, true>(a, st);
+        if (mt == 2) return launch_pw_mt<2, false, false, true>(a, st);
+        return fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
+    }
     if (mt == 4) return a.pool_ws ? launch_pw_mt<4, true, false>(a, st) : launch_pw_mt<4, false, false>(a, st);
     if (mt == 2) return a.pool_ws ? launch_pw_mt<2, true, false>(a, st) : launch_pw_mt<2, false, false>(a, st);
     return fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");

@@ -776,7 +776,7 @@ def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) 
 _conv2d_plain = conv2d
 
 
-def _kernel_name(taps, stride, tv, aff=False, pool=False) -> str:
+def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False) -> str:
     """The template instantiation rocprofv3 will report (minus the `void cmk::` prefix and the argument list)."""
     if not tv or tuple(tv[:3]) == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
@@ -786,9 +786,9 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False) -> str:
         return "conv_wino6_kernel<{}, {}>".format("true" if aff else "false", 1 if tv[2] == 2 else 0)
     wm, sc, wn = tv[:3]
     if wm == 8:
-        return "conv_pw_kernel<{}, {}, false>".format(wn, "true" if pool else "false")
+        return "conv_pw_kernel<{}, {}, false, {}>".format(wn, "true" if pool else "false", "true" if upres else "false")
     if wm == 9:
-        return "conv_pw_kernel<{}, false, true>".format(wn)
+        return "conv_pw_kernel<{}, false, true, false>".format(wn)
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)
     return "conv_igemm_kernel<{}, {}, {}, {}, {}, false>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
@@ -806,7 +806,7 @@ def conv2d(x, pc, y, **kw):  # noqa: F811
     descs = (ConvDesc * 1)()
     _fill_desc(descs[0], x, pc, y, kw.get("relu", False), kw.get("relu_upto"), kw.get("res"), kw.get("res_upsample", False), kw.get("in_relu", False))
     tv = _TUNED.get(_problem_key(descs, 1))
-    key = _kernel_name(taps, pc.stride, tv, pool=kw.get("pool") is not None and FUSE_POOL)
+    key = _kernel_name(taps, pc.stride, tv, pool=kw.get("pool") is not None and FUSE_POOL, upres=bool(kw.get("res_upsample")))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _conv2d_plain(x, pc, y, **kw)

@@ -54,7 +54,7 @@ typedef struct {
      * 9 taps x Cin/16 chunks, each A row gathered per tap — for maps too small to fill the spatial tiles (the 14->7 maskiou conv
      * maskiou_head.py:84, P6/P7 fpn.py:32-35); same K order, so again bitwise identical to the tiled variants.
      * tune_wm == 8 (with tune_wn in {4,2}) selects the pointwise GEMM kernel (conv_pw.hip) for a 1x1 conv with Cout > 224, Cin % 32 == 0,
-     * no fused input affine / input ReLU / upsampled residual / split-K: 64*tune_wn pixels x 128 output channels per workgroup, weights
+     * no fused input affine / input ReLU / split-K (the upsampled residual only with an even W): 64*tune_wn pixels x 128 output channels per workgroup, weights
      * fetched straight into registers (the packed layout is the same); again the same bits as the tiled variants.  It is also the
      * untuned default for such convs when they make at least 256 workgroups (vovnet.py:222-236 aggregation convs, the deconv).
      * tune_wm == 9 (tune_wn in {4,2}): the gather form of a 3x3 conv (stride 1|2) on that kernel — K walks 9 taps x Cin/16 chunks, rows

@@ -331,6 +331,41 @@ def test_conv_pointwise_gather_form(dev, case, mt):
     assert rc0 == 0 and torch.equal(y.t, y0.t)
 
 
+@pytest.mark.parametrize("mt", [4, 2])
+@pytest.mark.parametrize("case", [(2, 20, 36, 64, 256), (3, 10, 14, 96, 256), (1, 50, 80, 128, 288), (2, 6, 10, 32, 256)])
+def test_conv_pointwise_upsampled_residual(dev, cmk_lib, case, mt):
+    """The FPN lateral with the top-down add on the pointwise kernel (tune_wm 8 with res_mode 2): residual = nearest 2x upsampling of a
+    map of half the size (odd heights: the coarse map has ceil(H/2) rows), ragged last tile, Cout that is not a multiple of 128; an odd
+    width is refused (conv_igemm keeps it)."""
+    import ctypes
+    from centermask2_amd import _lib
+    n, h, w, cin, cout = case
+    x = _rand((n, cin, h, w), 101)
+    wt = _rand((cout, cin, 1, 1), 102, (2.0 / cin) ** 0.5)
+    shift = _rand((cout,), 103, 0.1)
+    hr, wr = (h + 1) // 2, (w + 1) // 2
+    res = _rand((n, hr, wr, cout + 8), 104).to(dev)
+    up = F.interpolate(res[..., 8:].permute(0, 3, 1, 2).cpu(), scale_factor=2.0, mode="nearest")[:, :, :h, :w]
+    ref = F.conv2d(x, wt, shift) + up
+    pc = ops.PackedConv(wt, None, shift, dev)
+    y = View(torch.full((n, h, w, cout), -5.0, device=dev))
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], ops.as_view(x.to(dev)), pc, y, False, None, View(res, 8, cout), True, False)
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 8, 32, mt
+    assert cmk_lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) == 0, cmk_lib.cmk_last_error()
+    torch.cuda.synchronize()
+    _close(y.nchw(), ref)
+    # odd width: refused
+    x2 = _rand((1, 32, 6, 9), 105)
+    y2 = View(torch.empty((1, 6, 9, 256), device=dev))
+    pc2 = ops.PackedConv(_rand((256, 32, 1, 1), 106), None, None, dev)
+    res2 = View(torch.zeros((1, 3, 5, 256), device=dev))
+    d2 = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d2[0], ops.as_view(x2.to(dev)), pc2, y2, False, None, res2, True, False)
+    d2[0].tune_wm, d2[0].tune_sc, d2[0].tune_wn = 8, 32, mt
+    assert cmk_lib.cmk_conv2d_nhwc(ctypes.byref(d2[0]), ops._stream()) != 0
+
+
 WINO6_CASES = [(2, 37, 45, 64, 128), (1, 16, 16, 256, 256), (1, 25, 40, 224, 224), (2, 14, 14, 256, 80), (1, 100, 160, 32, 5),
                (1, 12, 40, 128, 32), (1, 13, 41, 48, 33), (3, 5, 3, 32, 64), (1, 50, 80, 192, 192)]
 
