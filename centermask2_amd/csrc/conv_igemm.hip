@@ -900,9 +900,9 @@ static int setup_gn(ConvArgs& a, const cmk_conv_desc* d) {
 static int pointwise_mt(const cmk_conv_desc* d, int n) {
     const int cout32 = (d->Cout + 31) / 32;
     const long total_pix = (long)d->N * d->H * d->W;
-    if (d->ksize != 1 || n != 1 || cout32 <= 7 || (d->Cin & 31) || d->in_scale || d->in_relu || d->splitk > 1 || d->gn_ws ||
-        total_pix * d->x_cs * 4 >= (1L << 31))
+    if (d->ksize != 1 || n != 1 || cout32 <= 7 || (d->Cin & 31) || d->in_scale || d->in_relu || d->gn_ws || total_pix * d->x_cs * 4 >= (1L << 31))
         return 0;
+    if (d->splitk > 1 && (d->tune_wm != 8 || !d->splitk_ws || d->res_mode == 2 || d->pool_ws || (d->Cin >> 4) % (2 * d->splitk))) return 0;
     if (d->res_mode == 2 && ((d->W & 1) || d->pool_ws || (long)d->N * d->Hr * d->Wr * d->res_cs * 4 >= (1L << 31))) return 0;     // FPN top-down add: even widths
     if (d->tune_wm == 8) return (d->tune_wn == 4 || d->tune_wn == 2) ? d->tune_wn : 0;
     if (d->tune_wm || d->tune_sc || d->tune_wn) return 0;
@@ -917,14 +917,26 @@ static int gather_mt(const cmk_conv_desc* d, int n) {
     const int cout32 = (d->Cout + 31) / 32;
     const long in_pix = (long)d->N * d->H * d->W;
     const long out_pix = (long)d->N * (d->stride == 1 ? d->H : (d->H - 1) / 2 + 1) * (d->stride == 1 ? d->W : (d->W - 1) / 2 + 1);
-    if (d->ksize != 3 || n != 1 || (cout32 != 4 && cout32 <= 7) || (d->Cin & 31) || d->in_scale || d->in_relu || d->res_mode == 2 || d->splitk > 1 ||
+    if (d->ksize != 3 || n != 1 || (cout32 != 4 && cout32 <= 7) || (d->Cin & 31) || d->in_scale || d->in_relu || d->res_mode == 2 ||
         d->gn_ws || d->pool_ws || in_pix * d->x_cs * 4 >= (1L << 31) || d->H >= 32768 || d->W >= 32768)
         return 0;
+    if (d->splitk > 1 && (d->tune_wm != 9 || !d->splitk_ws || (9 * (d->Cin >> 4)) % (2 * d->splitk))) return 0;
     if (d->tune_wm == 9) return (d->tune_wn == 4 || d->tune_wn == 2) ? d->tune_wn : 0;
     if (d->tune_wm || d->tune_sc || d->tune_wn || d->stride != 2) return 0;
     const long ctiles = cdiv(cout32, 4);
     const long wg4 = ((out_pix + 255) / 256) * ctiles;
     return wg4 >= 1024 ? 4 : 0;          // measured (tools/bench_ga.py): stem_3 1.28x conv_igemm; the 14 -> 7 maskiou conv and P6/P7 stay on its split-K gather form
+}
+
+// the pointwise kernel's launch, followed by the split-K reduction when it left partial sums
+static int run_pointwise(ConvArgs& a, int mt, hipStream_t st) {
+    int rc = launch_pw(a, mt, st);
+    if (rc || a.ksplit <= 1) return rc;
+    const ConvProblem& p = a.p[0];
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((p.total_pix * (a.cout_pad >> 2) + 255) / 256, 256L * 32)), dim3(256), 0, st, a.ws, a.ksplit, p.total_pix,
+                       a.cout_pad, p.scale, p.shift, a.Cout, a.relu_upto, a.res_mode == 1 ? a.res : nullptr, a.res_cs, a.res_co, p.y, a.y_cs,
+                       a.y_co);
+    return check_launch("splitk_reduce");
 }
 
 static int run(const cmk_conv_desc* descs, int n, void* stream) {
@@ -974,14 +986,15 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         if (d->ksize != 1 || cout32 <= 7) return fail(CMK_EINVAL, "conv: pointwise variant needs a 1x1 conv with Cout > 224%s", "");
         a.cout_pad = cdiv(cout32, 4) * 128;
         a.gn_ws = d->gn_ws;
-        return launch_pw(a, d->tune_wn, st);
+        if (a.ksplit > 1 && !pointwise_mt(d, n)) return fail(CMK_EINVAL, "conv: pointwise variant: split-K not available for this conv%s", "");
+        return run_pointwise(a, d->tune_wn, st);
     }
     if (d->tune_wm == 9) {                             // gather form of a 3x3 conv on the pointwise GEMM kernel; tune_wn = accumulator rows per wave
         const int mt = gather_mt(d, n);
         if (!mt) return fail(CMK_EINVAL, "conv: pointwise gather variant not available for this conv%s", "");
         a.cout_pad = cdiv(cout32, 4) * 128;
         a.ga_stride = d->stride;
-        return launch_pw(a, mt, st);
+        return run_pointwise(a, mt, st);
     }
     if (d->tune_wm == 7) {                             // gather form: 3x3 (stride 1|2) as a flattened-pixel GEMM over 9x the K chunks
         if (d->ksize != 3 || n != 1 || d->res_mode == 2 || d->in_scale || (d->tune_wn != 1 && d->tune_wn != 2 && d->tune_wn != 4))

@@ -39,7 +39,9 @@ __device__ f32x4 pw_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) _
 // gather form).  Weights: conv_igemm's [tap][chunk][cout_pad][16]; same tap-major K order as its gather form (bit-identical to it).
 // UPRES: the FPN top-down add — the residual is the nearest-neighbour 2x upsampling of a map of half the size (a.res, a.Hr x a.Wr); needs an
 // even output width (then the pixel pairs the epilogue handles share one residual pixel).
-template <int MT, bool POOL, bool GA, bool UPRES>
+// SPLITK: blockIdx.y owns an (even) range of the K chunks and leaves raw partial sums in a.ws[z][pixel][cout_pad]; the caller runs
+// conv_igemm's reduce kernel (scale/shift/residual/ReLU there).  For the skinny GEMMs: MaskIoU fc1 (400 x 12544 x 1024), the 14 -> 7 conv.
+template <int MT, bool POOL, bool GA, bool UPRES, bool SPLITK>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     constexpr int BM = 64 * MT;         // pixels per workgroup
     constexpr int ABUF = BM * PST;      // floats per LDS buffer (rows of 16 channels, pitch 20)
@@ -60,7 +62,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     const long pix0 = (long)bx * BM;
     const int co0 = by * 128 + wn * 64;
     const int cin_chunks = a.Cin >> 4;
-    const int nchunks = GA ? 9 * cin_chunks : cin_chunks;     // even (host)
+    const int nchunks_all = GA ? 9 * cin_chunks : cin_chunks;     // even (host)
+    const int c_lo = SPLITK ? (int)((long)blockIdx.y * nchunks_all / a.ksplit) : 0;            // even bounds (host)
+    const int nchunks = SPLITK ? (int)((long)(blockIdx.y + 1) * nchunks_all / a.ksplit) : nchunks_all;      // one past this slice's last chunk
 
     // ---- activations: global -> registers -> LDS ------------------------------------------------------------------------------------
     // thread = (row tid>>2 (+64 per iteration), channel quad tid&3); a row past the last pixel gets an offset outside the resource
@@ -217,19 +221,19 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     // 4800 cycles per chunk.
     // The fences pin the order of the prologue's requests: the compiler's wait counts at the loop head are the minimum over the prologue's
     // and the loop's order, so a weight request scheduled late there makes every chunk wait for younger loads than it needs.
-    load_A(0);
+    load_A(c_lo);
     __builtin_amdgcn_sched_barrier(0);
-    load_B(0, 0);
+    load_B(c_lo, 0);
     __builtin_amdgcn_sched_barrier(0);
     store_A(0);
-    load_A(1);
+    load_A(c_lo + 1);
     __builtin_amdgcn_sched_barrier(0);
-    load_B(1, 1);
+    load_B(c_lo + 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     PW_STAMP(1);
     PW_SYNC;
     rd(avA, 0, 0);
-    for (int c = 0; c < nchunks; c += 2) {
+    for (int c = c_lo; c < nchunks; c += 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             rd(avB, u, 1);
@@ -255,6 +259,21 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
     // ---- epilogue: scale/shift (+same-size residual) (+ReLU), NHWC stores ------------------------------------------------------------------------
     // accumulator register r of lane half hh is pixel row (r & 3) + 8 * (r >> 2) + 4 * hh of the 32-pixel sub-tile; the lane is the cout
     const long wpix0 = pix0 + wm * (MT * 32);
+    if constexpr (SPLITK) {
+        float* wz = a.ws + ((long)blockIdx.y * total_pix + wpix0) * a.cout_pad + co0 + li;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (wpix0 + row < total_pix) {
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn)
+                        if (co0 + nn * 32 < a.cout_pad) wz[(long)row * a.cout_pad + nn * 32] = acc[m][nn][r];
+                }
+            }
+        return;
+    }
     float* ybase = P.y + wpix0 * a.y_cs;                                   // wave-uniform; rows are added to the lane offset below
     const float* rbase = a.res_mode == 1 ? a.res + wpix0 * a.res_cs : nullptr;
     const bool interior = (UPRES || a.res_mode == 0) && pix0 + BM <= total_pix && co0 + 64 <= a.Cout;
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int MT, bool POOL, bool GA, bool UPRES = false>
+template <int MT, bool POOL, bool GA, bool UPRES = false, bool SPLITK = false>
 static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * MT;
 #ifdef PW_TRACE
@@ -404,7 +423,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int LDS_BYTES = 2 * BM * PST * 4 + 4 * 64 * 8 + PW_LDS_EXTRA;      // PW_LDS_EXTRA: experiments with one workgroup per CU
     static DeviceOnce once;
     int rc0 = once.run([]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT, POOL, GA, UPRES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT, POOL, GA, UPRES, SPLITK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_pw: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     });
     if (rc0) return rc0;
@@ -417,7 +436,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     const long tiles = (p.total_pix + BM - 1) / BM;
     a.total_tiles = (int)tiles;
     a.grid_y = a.cout_pad / 128;
-    hipLaunchKernelGGL((conv_pw_kernel<MT, POOL, GA, UPRES>), dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y)), dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_pw_kernel<MT, POOL, GA, UPRES, SPLITK>), dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y), SPLITK ? a.ksplit : 1), dim3(256), LDS_BYTES, st, a);
     return check_launch("conv_pw");
 }
 
@@ -425,8 +444,17 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
 // the gather form of a 3x3 conv (a.w then is conv_igemm's 9-tap packing), 0 for a 1x1 conv.
 int launch_pw(ConvArgs& a, int mt, hipStream_t st) {
     const ConvProblem& p = a.p[0];
-    if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws || a.ksplit > 1)
-        return fail(CMK_EINVAL, "conv_pw: one problem, no input affine / input ReLU / GroupNorm statistics / split-K%s", "");
+    if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws)
+        return fail(CMK_EINVAL, "conv_pw: one problem, no input affine / input ReLU / GroupNorm statistics%s", "");
+    if (a.ksplit > 1) {             // raw partial sums into a.ws; the caller reduces
+        const int nch = (a.ga_stride ? 9 : 1) * (a.Cin >> 4);
+        if (!a.ws || a.res_mode == 2 || a.pool_ws || nch % (2 * a.ksplit))
+            return fail(CMK_EINVAL, "conv_pw: split-K needs a workspace, K chunks %% (2*splitk) == 0, no upsampled residual / pooled sums%s", "");
+        if (a.ga_stride) return mt == 4 ? launch_pw_mt<4, false, true, false, true>(a, st) : mt == 2 ? launch_pw_mt<2, false, true, false, true>(a, st)
+                                                                                                      : fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
+        return mt == 4 ? launch_pw_mt<4, false, false, false, true>(a, st) : mt == 2 ? launch_pw_mt<2, false, false, false, true>(a, st)
+                                                                                     : fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
+    }
     if (a.res_mode == 2) {          // FPN top-down add
         if (a.ga_stride || a.pool_ws || (p.Wo & 1) || (long)p.N * a.Hr * a.Wr * a.res_cs * 4 >= (1L << 31))
             return fail(CMK_EINVAL, "conv_pw: the upsampled residual needs a 1x1 conv, an even output width, no pooled sums, a residual below 2 GiB%s", "");

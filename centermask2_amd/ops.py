@@ -291,9 +291,9 @@ def _tune(descs, n, key) -> None:
     if small and d0.ksize == 3:
         cands += [(7, 32, wn, sk) for wn in (1, 2, 4) for sk in sks]      # gather form
     if d0.ksize == 3:
-        cands += [(9, 32, 4, 1), (9, 32, 2, 1)]   # gather form of a 3x3 conv on the pointwise GEMM kernel (conv_pw.hip GA); same K order as the direct kernels
+        cands += [(9, 32, mt, sk) for mt in (4, 2) for sk in sks]   # gather form of a 3x3 conv on the pointwise GEMM kernel (conv_pw.hip GA)
     if d0.ksize == 1:
-        cands += [(8, 32, 4, 1), (8, 32, 2, 1)]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
+        cands += [(8, 32, mt, sk) for mt in (4, 2) for sk in sks]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
     if ALLOW_WINOGRAD:
         cands += [(5, 16, 2, 1)]                  # fused Winograd F(2x2,3x3)
         cands += [(6, 16, 1, 1), (6, 16, 2, 1)]   # fused Winograd F(4x4,3x3): map tiles / pairs of RoI maps (the library rejects what does not apply)

@@ -54,12 +54,12 @@ typedef struct {
      * 9 taps x Cin/16 chunks, each A row gathered per tap — for maps too small to fill the spatial tiles (the 14->7 maskiou conv
      * maskiou_head.py:84, P6/P7 fpn.py:32-35); same K order, so again bitwise identical to the tiled variants.
      * tune_wm == 8 (with tune_wn in {4,2}) selects the pointwise GEMM kernel (conv_pw.hip) for a 1x1 conv with Cout > 224, Cin % 32 == 0,
-     * no fused input affine / input ReLU / split-K (the upsampled residual only with an even W): 64*tune_wn pixels x 128 output channels per workgroup, weights
+     * no fused input affine / input ReLU (the upsampled residual only with an even W; split-K with K chunks % (2*splitk) == 0): 64*tune_wn pixels x 128 output channels per workgroup, weights
      * fetched straight into registers (the packed layout is the same); again the same bits as the tiled variants.  It is also the
      * untuned default for such convs when they make at least 256 workgroups (vovnet.py:222-236 aggregation convs, the deconv).
      * tune_wm == 9 (tune_wn in {4,2}): the gather form of a 3x3 conv (stride 1|2) on that kernel — K walks 9 taps x Cin/16 chunks, rows
      * gathered per tap with bounds-checked loads; Cout in 97..128 or > 224, Cin % 32 == 0, one problem, no fused affine / upsampled
-     * residual / split-K; bitwise identical to the tune_wm 7 form; the untuned default for stride-2 convs of at least 1024 workgroups
+     * residual; bitwise identical to the tune_wm 7 form; the untuned default for stride-2 convs of at least 1024 workgroups
      * of 256 pixels (stem_3 vovnet.py:412). */
     int tune_wm; int tune_sc; int tune_wn;
     /* tune_wm == 5 selects the fused Winograd F(2x2,3x3) kernel (3x3 stride 1, no residual; the default for such convs when w_wino

@@ -366,6 +366,21 @@ def test_conv_pointwise_upsampled_residual(dev, cmk_lib, case, mt):
     assert cmk_lib.cmk_conv2d_nhwc(ctypes.byref(d2[0]), ops._stream()) != 0
 
 
+@pytest.mark.parametrize("case", [(1, 1, 37, 12544, 1024, 1, 1, (8, 32, 2, 8)), (1, 1, 400, 1024, 1024, 1, 1, (8, 32, 4, 2)), (6, 14, 14, 256, 256, 3, 2, (9, 32, 2, 4)),
+                                  (2, 13, 20, 256, 256, 3, 2, (9, 32, 2, 8)), (2, 9, 11, 64, 320, 3, 1, (9, 32, 4, 2))])
+def test_conv_pointwise_split_k(dev, case):
+    """Split-K on the pointwise kernel (both the 1x1 and the gather form): raw partial sums + conv_igemm's reduce kernel."""
+    n, h, w, cin, cout, k, stride, tv = case
+    x = _rand((n, cin, h, w), 111)
+    wt = _rand((cout, cin, k, k), 112, (2.0 / (cin * k * k)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(113)) + 0.5
+    shift = _rand((cout,), 114, 0.1)
+    ref = F.relu(F.conv2d(x, wt, None, stride=stride, padding=k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    rc, y = _run_variant(dev, x, wt, scale, shift, tv, stride=stride)
+    assert rc == 0
+    _close(y.nchw(), ref)
+
+
 WINO6_CASES = [(2, 37, 45, 64, 128), (1, 16, 16, 256, 256), (1, 25, 40, 224, 224), (2, 14, 14, 256, 80), (1, 100, 160, 32, 5),
                (1, 12, 40, 128, 32), (1, 13, 41, 48, 33), (3, 5, 3, 32, 64), (1, 50, 80, 192, 192)]
 
