@@ -785,10 +785,11 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False) -> str:
     if tv[0] == 6:
         return "conv_wino6_kernel<{}, {}>".format("true" if aff else "false", 1 if tv[2] == 2 else 0)
     wm, sc, wn = tv[:3]
+    sk = "true" if (len(tv) > 3 and tv[3] > 1) else "false"
     if wm == 8:
-        return "conv_pw_kernel<{}, {}, false, {}>".format(wn, "true" if pool else "false", "true" if upres else "false")
+        return "conv_pw_kernel<{}, {}, false, {}, {}>".format(wn, "true" if pool else "false", "true" if upres else "false", sk)
     if wm == 9:
-        return "conv_pw_kernel<{}, false, true, false>".format(wn)
+        return "conv_pw_kernel<{}, false, true, false, {}>".format(wn, sk)
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)
     return "conv_igemm_kernel<{}, {}, {}, {}, {}, false>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)
