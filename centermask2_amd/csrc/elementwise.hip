@@ -160,6 +160,21 @@ __global__ __launch_bounds__(256) void maxpool3_kernel(const float* __restrict__
     }
 }
 
+// MaxPool2d(kernel 1, stride 2) = every second pixel (d2's LastLevelMaxPool, the top block of build_vovnet_fpn_backbone vovnet.py:504-524)
+__global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ x, int x_cs, int x_co, float* __restrict__ y, int y_cs, int y_co,
+                                                        int N, int H, int W, int Ho, int Wo, int C4) {
+    long total = (long)N * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = (int)(i % C4);
+        long p = i / C4;
+        int ow = (int)(p % Wo);
+        int oh = (int)((p / Wo) % Ho);
+        int n = (int)(p / ((long)Wo * Ho));
+        *reinterpret_cast<f32x4*>(y + p * y_cs + y_co + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(x + (((long)n * H + 2 * oh) * W + 2 * ow) * x_cs + x_co + c4 * 4);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // eSE (vovnet.py:247-260).  Stage 1: per (image, pixel chunk) channel sums (deterministic: fixed order, no atomics).
 // Stage 2: mean -> fc (C x C mat-vec, one wave per output, wave64 shuffle reduction) -> relu6(v+3)/6.
@@ -195,39 +210,41 @@ __global__ __launch_bounds__(256) void ese_fc_kernel(const float* __restrict__ w
                                                     int chunks) {
     // 16 outputs per workgroup.  Stage 1 reduces the per-chunk partial sums to the channel means: the chunk range is split over
     // `parts` thread groups (16 B per thread per chunk, independent loads), folded through LDS.  Stage 2: one wave per output.
-    extern __shared__ float sm[];  // [parts][C] partials, then mean in row 0
+    // (float64 from the partial sums on, as in ese_fc_pooled_kernel)
+    extern __shared__ double smd[];  // [parts][C] partials, then mean in row 0
     const int n = blockIdx.y;
     const int G = C >> 2;
     const int parts = G >= 256 ? 1 : 256 / G;
     const float* wsn = ws + (long)n * chunks * C;
     for (int gi = threadIdx.x; gi < G * parts; gi += 256) {
         const int g = gi % G, part = gi / G;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 8
         for (int k = part; k < chunks; k += parts) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(wsn + (long)k * C + g * 4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wsn + (long)k * C + g * 4);
+            s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
         }
-        *reinterpret_cast<f32x4*>(sm + part * C + g * 4) = s;
+        double* o = smd + part * C + g * 4;
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int part = 0; part < parts; ++part) s += sm[part * C + c];
-        sm[c] = s / (float)HW;   // row 0 is only read by its own thread above
+        double s = 0.0;
+        for (int part = 0; part < parts; ++part) s += smd[part * C + c];
+        smd[c] = s / (double)HW;   // row 0 is only read by its own thread above
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int o = blockIdx.x * 16 + wave; o < min(C, (int)(blockIdx.x + 1) * 16); o += 4) {
         const float* wr = fc_w + (long)o * C;
-        float s = 0.f;
+        double s = 0.0;
         for (int c = lane * 4; c < C; c += 256) {
             f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-            s += wv.x * sm[c] + wv.y * sm[c + 1] + wv.z * sm[c + 2] + wv.w * sm[c + 3];
+            s += (double)wv.x * smd[c] + (double)wv.y * smd[c + 1] + (double)wv.z * smd[c + 2] + (double)wv.w * smd[c + 3];
         }
         s = wave_sum(s);
         if (lane == 0) {
-            float v = s + fc_b[o] + 3.0f;
+            float v = (float)(s + (double)fc_b[o] + 3.0);
             gate[(long)n * C + o] = fminf(fmaxf(v, 0.f), 6.f) / 6.0f;
         }
     }
@@ -237,7 +254,11 @@ __global__ __launch_bounds__(256) void ese_fc_kernel(const float* __restrict__ w
 // its first pixel, 2g+1 = rows of block g in the next image.  Stage 1 (channel means) differs from ese_fc_kernel, stage 2 is the same.
 __global__ __launch_bounds__(256) void ese_fc_pooled_kernel(const float* __restrict__ rec, int rows, const float* __restrict__ fc_w,
                                                            const float* __restrict__ fc_b, float* __restrict__ gate, int HW, int C) {
-    extern __shared__ float sm[];  // [parts][C] partials, then mean in row 0
+    // The records are fp32 sums of at most `rows` values each; everything downstream of them — the sum over the records, the mean and
+    // the C x C fully-connected layer — is accumulated in float64 in a fixed order (a few thousand adds per image: free), so the gate
+    // carries the rounding of the records and of one final conversion only (the detection order of near-tied scores
+    // depends on summation-order noise upstream; this removes this kernel's share of it).
+    extern __shared__ double smd[];  // [parts][C] partials, then the mean in row 0
     const int n = blockIdx.y;
     const int G = C >> 2;
     const int parts = G >= 256 ? 1 : 256 / G;
@@ -246,33 +267,37 @@ __global__ __launch_bounds__(256) void ese_fc_pooled_kernel(const float* __restr
     const long first = (g0 * rows == p0) ? 2 * g0 : 2 * g0 + 1;          // the record of block g0 that holds this image's rows
     for (int gi = threadIdx.x; gi < G * parts; gi += 256) {
         const int g = gi % G, part = gi / G;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        if (part == 0) s = *reinterpret_cast<const f32x4*>(rec + first * C + g * 4);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (part == 0) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rec + first * C + g * 4);
+            s0 = v.x; s1 = v.y; s2 = v.z; s3 = v.w;
+        }
 #pragma unroll 8
         for (long k = g0 + 1 + part; k <= g1; k += parts) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(rec + 2 * k * C + g * 4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rec + 2 * k * C + g * 4);
+            s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
         }
-        *reinterpret_cast<f32x4*>(sm + part * C + g * 4) = s;
+        double* o = smd + part * C + g * 4;
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int part = 0; part < parts; ++part) s += sm[part * C + c];
-        sm[c] = s / (float)HW;   // row 0 is only read by its own thread above
+        double s = 0.0;
+        for (int part = 0; part < parts; ++part) s += smd[part * C + c];
+        smd[c] = s / (double)HW;   // row 0 is only read by its own thread above
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int o = blockIdx.x * 16 + wave; o < min(C, (int)(blockIdx.x + 1) * 16); o += 4) {
         const float* wr = fc_w + (long)o * C;
-        float s = 0.f;
+        double s = 0.0;
         for (int c = lane * 4; c < C; c += 256) {
             f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-            s += wv.x * sm[c] + wv.y * sm[c + 1] + wv.z * sm[c + 2] + wv.w * sm[c + 3];
+            s += (double)wv.x * smd[c] + (double)wv.y * smd[c + 1] + (double)wv.z * smd[c + 2] + (double)wv.w * smd[c + 3];
         }
         s = wave_sum(s);
         if (lane == 0) {
-            float v = s + fc_b[o] + 3.0f;
+            float v = (float)(s + (double)fc_b[o] + 3.0);
             gate[(long)n * C + o] = fminf(fmaxf(v, 0.f), 6.f) / 6.0f;
         }
     }
@@ -529,6 +554,17 @@ extern "C" int cmk_maxpool3x3s2_ceil_nhwc(const float* x, int x_cs, int x_co, fl
     return check_launch("maxpool3");
 }
 
+extern "C" int cmk_maxpool1x1s2_nhwc(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int H, int W, int C, void* stream) {
+    if (!x || !y) return fail(CMK_EINVAL, "maxpool1x1s2: null pointer%s", "");
+    if ((C & 3) || (x_cs & 3) || (x_co & 3) || (y_cs & 3) || (y_co & 3) || N < 1 || H < 1 || W < 1)
+        return fail(CMK_EINVAL, "maxpool1x1s2: channels must be multiples of 4, N, H, W >= 1%s", "");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    long total = (long)N * Ho * Wo * (C >> 2);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_cs, x_co, y, y_cs, y_co, N, H, W, Ho, Wo,
+                       C >> 2);
+    return check_launch("maxpool1x1s2");
+}
+
 extern "C" int cmk_ese_gate(const float* x, int x_cs, int x_co, const float* fc_w, const float* fc_b, float* gate, float* ws,
                             int ws_chunks, int N, int HW, int C, void* stream) {
     if (!x || !fc_w || !fc_b || !gate || !ws) return fail(CMK_EINVAL, "ese_gate: null pointer%s", "");
@@ -539,7 +575,7 @@ extern "C" int cmk_ese_gate(const float* x, int x_cs, int x_co, const float* fc_
     hipLaunchKernelGGL(ese_partial_kernel, dim3(ws_chunks, N), dim3(256), lds1, (hipStream_t)stream, x, x_cs, x_co, ws, HW, C, ws_chunks);
     int rc = check_launch("ese_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(ese_fc_kernel, dim3(cdiv(C, 16), N), dim3(256), lds1, (hipStream_t)stream, ws, fc_w, fc_b,
+    hipLaunchKernelGGL(ese_fc_kernel, dim3(cdiv(C, 16), N), dim3(256), 2 * lds1 /* doubles */, (hipStream_t)stream, ws, fc_w, fc_b,
                        gate, HW, C, ws_chunks);
     return check_launch("ese_fc");
 }
@@ -549,7 +585,7 @@ extern "C" int cmk_ese_gate_pooled(const float* pool_ws, int rows, const float* 
     if ((C & 3) || rows < 1 || HW < rows || N < 1) return fail(CMK_EINVAL, "ese_gate_pooled: bad shape (C %% 4, H*W >= rows)%s", "");
     const int G = C >> 2;
     const int parts = G >= 256 ? 1 : 256 / G;
-    hipLaunchKernelGGL(ese_fc_pooled_kernel, dim3(cdiv(C, 16), N), dim3(256), (size_t)parts * C * sizeof(float), (hipStream_t)stream, pool_ws, rows,
+    hipLaunchKernelGGL(ese_fc_pooled_kernel, dim3(cdiv(C, 16), N), dim3(256), (size_t)parts * C * sizeof(double), (hipStream_t)stream, pool_ws, rows,
                        fc_w, fc_b, gate, HW, C);
     return check_launch("ese_fc_pooled");
 }

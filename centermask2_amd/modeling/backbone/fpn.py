@@ -14,7 +14,7 @@ from ... import ops
 from ...ops import View
 from ..base import Backbone, HipModule
 
-__all__ = ["FPN", "LastLevelP6P7", "LastLevelP6"]
+__all__ = ["FPN", "LastLevelP6P7", "LastLevelP6", "LastLevelMaxPool"]
 
 
 class LastLevelP6P7(nn.Module):
@@ -32,6 +32,16 @@ class LastLevelP6(nn.Module):
         self.num_levels = 1
         self.in_feature = in_features
         self.p6 = nn.Conv2d(in_channels, out_channels, 3, 2, 1)
+
+
+class LastLevelMaxPool(nn.Module):
+    """d2's top block of the plain FPN backbone (vovnet.py:504-524): p6 = max_pool2d(p5, kernel 1, stride 2) — every second pixel of p5;
+    no parameters."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_levels = 1
+        self.in_feature = "p5"
 
 
 class FPN(Backbone):
@@ -71,7 +81,7 @@ class FPN(Backbone):
             lat, out = getattr(self, "fpn_lateral{}".format(st)), getattr(self, "fpn_output{}".format(st))
             P["lat{}".format(st)] = ops.PackedConv(lat.weight, None, lat.bias, dev)
             P["out{}".format(st)] = ops.PackedConv(out.weight, None, out.bias, dev)
-        if self.top_block is not None:
+        if self.top_block is not None and not isinstance(self.top_block, LastLevelMaxPool):
             P["p6"] = ops.PackedConv(self.top_block.p6.weight, None, self.top_block.p6.bias, dev, stride=2)
             if self.top_block.num_levels == 2:
                 P["p7"] = ops.PackedConv(self.top_block.p7.weight, None, self.top_block.p7.bias, dev, stride=2)
@@ -93,7 +103,7 @@ class FPN(Backbone):
             src_name = self.top_block.in_feature
             src = bu[src_name] if src_name in bu else results[src_name]
             top = self._stages[-1]
-            p6 = ops.conv_out(src, P["p6"])
+            p6 = ops.maxpool1x1s2(src) if isinstance(self.top_block, LastLevelMaxPool) else ops.conv_out(src, P["p6"])
             results["p{}".format(top + 1)] = p6
             if self.top_block.num_levels == 2:
                 results["p{}".format(top + 2)] = ops.conv_out(p6, P["p7"], in_relu=True)     # p7(relu(p6)), fpn.py:34

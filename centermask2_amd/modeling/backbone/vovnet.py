@@ -20,7 +20,7 @@ from ...ops import View
 from ...registry import BACKBONE_REGISTRY
 from ...structures import ShapeSpec
 from ..base import Backbone, FrozenBatchNorm2d, HipModule
-from .fpn import FPN, LastLevelP6, LastLevelP6P7
+from .fpn import FPN, LastLevelMaxPool, LastLevelP6, LastLevelP6P7
 
 __all__ = ["VoVNet", "build_vovnet_backbone", "build_fcos_vovnet_fpn_backbone", "_STAGE_SPECS"]
 
@@ -283,6 +283,15 @@ def _pool_out(n: int) -> int:
 def build_vovnet_backbone(cfg, input_shape):
     """vovnet.py:492-501."""
     return VoVNet(cfg, input_shape.channels, out_features=cfg.MODEL.VOVNET.OUT_FEATURES)
+
+
+@BACKBONE_REGISTRY.register()
+def build_vovnet_fpn_backbone(cfg, input_shape: ShapeSpec):
+    """vovnet.py:504-524: VoVNet + FPN with d2's LastLevelMaxPool on top (p6 = every second pixel of p5) — the backbone of the
+    reference's Mask R-CNN style configs; the FCOS configs use build_fcos_vovnet_fpn_backbone below."""
+    bottom_up = build_vovnet_backbone(cfg, input_shape)
+    return FPN(bottom_up=bottom_up, in_features=cfg.MODEL.FPN.IN_FEATURES, out_channels=cfg.MODEL.FPN.OUT_CHANNELS, norm=cfg.MODEL.FPN.NORM,
+               top_block=LastLevelMaxPool(), fuse_type=cfg.MODEL.FPN.FUSE_TYPE)
 
 
 @BACKBONE_REGISTRY.register()

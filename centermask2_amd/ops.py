@@ -524,6 +524,16 @@ def maxpool3x3s2_ceil(x: View, y: Optional[View] = None, gate: Optional[torch.Te
     return y
 
 
+def maxpool1x1s2(x: View) -> View:
+    """MaxPool2d(kernel_size=1, stride=2): every second pixel (d2 LastLevelMaxPool; vovnet.py:504-524)."""
+    lib = _lib.load()
+    _need_gpu(x.t, "maxpool1x1s2")
+    n, h, w = x.nhw
+    y = View(torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, x.c), dtype=torch.float32, device=x.t.device))
+    check(lib.cmk_maxpool1x1s2_nhwc(x.t.data_ptr(), x.cs, x.co, y.t.data_ptr(), y.cs, y.co, n, h, w, x.c, _stream()), "cmk_maxpool1x1s2_nhwc")
+    return y
+
+
 def _ese_chunks(hw: int, c: int) -> int:
     """Pixel chunks per image for the eSE average pool: ~32K elements per workgroup so even the 25x40 stage fills the chip."""
     return max(1, min(256, (hw * c) // 32768))

@@ -24,7 +24,8 @@ extern "C" {
 #define CMK_EINVAL (-1)   /* bad argument / unsupported shape */
 #define CMK_ELAUNCH (-2)  /* HIP launch error */
 
-int cmk_version(void);                 /* ABI version, currently 2 (2: cmk_conv_desc.w_wino6, cmk_groupnorm_affine_tiles takes record counts) */
+int cmk_version(void);                 /* ABI version, currently 3 (2: cmk_conv_desc.w_wino6, cmk_groupnorm_affine_tiles takes record counts;
+                                          3: cmk_conv_desc.pool_ws, cmk_ese_gate_pooled, cmk_pack_records); additions since keep 3 */
 const char* cmk_arch(void);            /* "gfx950" */
 const char* cmk_last_error(void);
 
@@ -131,6 +132,10 @@ int cmk_stem_conv_nchw3(const float* x, const float* w /* [27][Cout] */, const f
 /* gate: optional (N*C) non-negative channel gate applied after the max (the eSE scale of the producer block, folded in). */
 int cmk_maxpool3x3s2_ceil_nhwc(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co,
                                int N, int H, int W, int C, const float* gate, void* stream);
+
+/* MaxPool2d(kernel 1, stride 2): every second pixel — d2's LastLevelMaxPool, the top block build_vovnet_fpn_backbone (vovnet.py:504-524)
+ * hands to the FPN; Ho = (H-1)/2 + 1, Wo = (W-1)/2 + 1. */
+int cmk_maxpool1x1s2_nhwc(const float* x, int x_cs, int x_co, float* y, int y_cs, int y_co, int N, int H, int W, int C, void* stream);
 
 /* ---- eSE (vovnet.py:247-260): gate = relu6(W * mean_HW(x) + b + 3) / 6 ; y = x * gate (+ identity) ------------
  * ws: N * ese_chunks * C floats of workspace for the two-stage mean.                                        */

@@ -24,3 +24,21 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Observed maximum errors of the parity checks (tests/helpers.py: close / close_abs), so the margin to the bar is on record."""
+    try:
+        from tests import helpers
+    except Exception:
+        return
+    if not helpers.OBSERVED:
+        return
+    terminalreporter.write_line("observed max errors (what: err):")
+    for k in sorted(helpers.OBSERVED):
+        terminalreporter.write_line("  {}: {:.3e}".format(k, helpers.OBSERVED[k]))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "observed_errors.json"), "w") as f:
+            json.dump(helpers.OBSERVED, f, indent=1, sort_keys=True)

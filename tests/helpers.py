@@ -10,14 +10,37 @@ def golden(name):
     return torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=True)
 
 
+OBSERVED = {}      # what -> largest absolute error seen this session (printed by conftest at the end of a run: the margin on record)
+
+
+def _record(what, err):
+    if what:
+        OBSERVED[what] = max(OBSERVED.get(what, 0.0), float(err))
+
+
 def close(got, ref, tol, what=""):
+    """Quantities with a natural scale (pixels, features of a single random op): max abs err <= tol * max(1, max|ref|)."""
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     assert got.shape == ref.shape, (what, tuple(got.shape), tuple(ref.shape))
     if got.numel() == 0:
         return 0.0
     err = (got - ref).abs().max().item()
     bound = tol * max(1.0, ref.abs().max().item())
+    _record(what + " (rel)", err / max(1.0, ref.abs().max().item()))
     assert err <= bound, "{}: max abs err {:.3e} > {:.3e}".format(what, err, bound)
+    return err
+
+
+def close_abs(got, ref, tol, what=""):
+    """north_star's bar for logits / regression / centerness / mask logits / scores: max ABSOLUTE error <= tol, whatever the
+    magnitude of the reference (no max|ref| factor)."""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, tuple(got.shape), tuple(ref.shape))
+    if got.numel() == 0:
+        return 0.0
+    err = (got - ref).abs().max().item()
+    _record(what + " (abs)", err)
+    assert err <= tol, "{}: max abs err {:.3e} > {:.3e} (absolute)".format(what, err, tol)
     return err
 
 

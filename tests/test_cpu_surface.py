@@ -82,6 +82,18 @@ def test_plugins_register_and_build_with_reference_keys():
         assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
     shp = model.backbone.output_shape()
     assert list(shp) == ["p3", "p4", "p5", "p6", "p7"] and shp["p6"].stride == 64 and model.backbone.size_divisibility == 32
+    # build_vovnet_fpn_backbone (vovnet.py:504-524): FPN + LastLevelMaxPool; the parameter names the reference's builder produced
+    from centermask2_amd.structures import ShapeSpec
+    from .helpers import golden
+    assert "build_vovnet_fpn_backbone" in BACKBONE_REGISTRY
+    cfg = get_cfg()
+    cfg.merge_from_file(config_path("centermask_V_39_eSE_FPN_ms_3x.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu"])
+    bb = BACKBONE_REGISTRY.get("build_vovnet_fpn_backbone")(cfg, ShapeSpec(channels=3))
+    g = golden("vovnet_fpn_maxpool")
+    assert set(bb.state_dict().keys()) == set(g["keys"])
+    shp = bb.output_shape()
+    assert list(shp) == ["p3", "p4", "p5", "p6"] and [shp[k].stride for k in shp] == g["strides"].tolist()
 
 
 def test_product_path_fails_loudly_without_gpu():

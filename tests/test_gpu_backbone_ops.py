@@ -1,5 +1,5 @@
 """-m gpu: HIP kernels of the backbone/towers through the C ABI vs the oracle's torch fp32 ops (same seeded inputs).
-Tolerance: fp32 logits/features within 1e-3 abs (north_star); here 2e-4 * max|ref| for single ops."""
+Tolerance: fp32 logits/features within 1e-3 ABSOLUTE (north_star) and, for single ops, also within 2e-4 * max(1, max|ref|)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -19,7 +19,7 @@ def _close(got, ref, rel=2e-4):
     got, ref = got.float().cpu(), ref.float().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
     err = (got - ref).abs().max().item()
-    bound = rel * max(1.0, ref.abs().max().item())
+    bound = min(1e-3, rel * max(1.0, ref.abs().max().item()))      # never looser than north_star's absolute 1e-3
     assert err <= bound, "max abs err {} > {}".format(err, bound)
 
 

@@ -8,7 +8,7 @@ from centermask2_amd import ops
 from centermask2_amd.ops import View
 from oracle import centermask_oracle as O
 
-from .helpers import close, golden
+from .helpers import close, close_abs, golden
 
 pytestmark = pytest.mark.gpu
 STRIDES = (8, 16, 32, 64, 128)
@@ -215,19 +215,19 @@ def test_roi_heads_match_reference_fixture(dev):
     close(out["roi_feat"][rows].permute(0, 3, 1, 2), g["roi_feat"], 1e-5, "roi_feat")
     cls = torch.cat([g["img0"]["classes"], g["img1"]["classes"]])
     sel = g["mask_logits"][torch.arange(len(rows)), cls]
-    close(out["mask_logits_selected"][rows], sel, 1e-3, "selected mask logits")
-    close(out["maskiou"][rows], g["maskiou"], 1e-3, "maskiou")
+    close_abs(out["mask_logits_selected"][rows], sel, 1e-3, "selected mask logits")
+    close_abs(out["maskiou"][rows], g["maskiou"], 1e-3, "maskiou")
     start = 0
     for i in range(2):
         r = g["img{}".format(i)]
         m = r["boxes"].shape[0]
-        close(out["pred_masks"][i, :m], r["pred_masks"], 1e-3, "pred_masks")
-        close(out["mask_scores"][i, :m], r["mask_scores"], 1e-3, "mask_scores")
+        close_abs(out["pred_masks"][i, :m], r["pred_masks"], 1e-3, "pred_masks")
+        close_abs(out["mask_scores"][i, :m], r["mask_scores"], 1e-3, "mask_scores")
     # all-class predictor through the reference signature
     full = model.roi_heads.mask_head(g["roi_feat"].to(dev))
-    close(full, g["mask_logits"], 1e-3, "mask logits, all classes")
+    close_abs(full, g["mask_logits"], 1e-3, "mask logits, all classes")
     miou = model.roi_heads.maskiou_head(g["roi_feat"].to(dev), torch.cat([g["img0"]["pred_masks"], g["img1"]["pred_masks"]]).to(dev))
-    close(miou, g["maskiou"], 1e-3, "maskiou via reference signature")
+    close_abs(miou, g["maskiou"], 1e-3, "maskiou via reference signature")
 
 
 def test_pooler_by_area_and_roialign_v1_match_reference(dev):

@@ -1,11 +1,18 @@
 """-m gpu: the plugins end to end against the fixtures the reference's own modules produced (tests/golden).
-Tolerances: features/logits 1e-3 abs-or-rel (north_star "within 1e-3 fp32"), labels/locations exact."""
+Tolerances: features, logits, regression, centerness, mask probabilities and scores within 1e-3 ABSOLUTE (north_star "within 1e-3
+fp32"; helpers.close_abs, no max|ref| factor; the observed maxima are printed at the end of the run), boxes in pixels within
+2e-5 x max|coordinate|, labels/locations exact."""
 import pytest
 import torch
 
-from .helpers import build_gpu_model, close, golden, match_detections
+from .helpers import build_gpu_model, close, close_abs, golden, match_detections
 
 pytestmark = pytest.mark.gpu
+
+
+# Rank swaps allowed between detections whose scores differ by less than this (helpers.match_detections); 0 would demand the
+# reference's exact order.  Image 0 of the fixtures holds two detections 2.3e-6 apart (ranks 8 and 9): see DESIGN.md section 1.
+ORDER_TOL = float(__import__("os").environ.get("CMK_TEST_ORDER_TOL", "1e-5"))      # the env var is for experiments (0 = the reference's exact order)
 
 
 @pytest.fixture(scope="module")
@@ -19,7 +26,7 @@ def test_vovnet_odd_size_matches_reference(dev, model):
     torch.cuda.synchronize()
     for k in ("stage3", "stage4", "stage5"):
         assert tuple(out[k].shape) == tuple(g[k].shape)
-        close(out[k], g[k], 1e-4, k)
+        close_abs(out[k], g[k], 1e-3, "features " + k)
 
 
 def test_backbone_fpn_matches_reference(dev, model):
@@ -28,9 +35,31 @@ def test_backbone_fpn_matches_reference(dev, model):
     torch.cuda.synchronize()
     assert list(out.keys()) == ["p3", "p4", "p5", "p6", "p7"]
     for k in out:
-        close(out[k], g[k], 1e-4, k)
+        close_abs(out[k], g[k], 1e-3, "features " + k)
     shp = model.backbone.output_shape()
     assert shp["p3"].stride == 8 and shp["p7"].stride == 128 and shp["p5"].channels == 256 and model.backbone.size_divisibility == 32
+
+
+def test_vovnet_fpn_maxpool_backbone_matches_reference(dev):
+    """build_vovnet_fpn_backbone (vovnet.py:504-524: FPN + d2 LastLevelMaxPool) against what the reference's own builder produced
+    (tests/golden/make_golden_fpn_maxpool.py); p6 is every second pixel of p5, bit for bit."""
+    from centermask2_amd import synthetic as S
+    from centermask2_amd.config import get_cfg, config_path
+    from centermask2_amd.registry import BACKBONE_REGISTRY
+    from centermask2_amd.structures import ShapeSpec
+    g = golden("vovnet_fpn_maxpool")
+    cfg = get_cfg()
+    cfg.merge_from_file(config_path("centermask_V_39_eSE_FPN_ms_3x.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.BACKBONE.NAME", "build_vovnet_fpn_backbone"])
+    bb = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, ShapeSpec(channels=3)).eval()
+    sd = S.make_synthetic_state_dict("V-39-eSE", 0)
+    bb.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.") and not k.startswith("backbone.top_block.")})
+    out = bb.to(dev)(g["x"].to(dev))
+    torch.cuda.synchronize()
+    assert list(out.keys()) == ["p3", "p4", "p5", "p6"]
+    for k in out:
+        close_abs(out[k], g[k], 1e-3, "fpn+maxpool features " + k)
+    assert torch.equal(out["p6"], out["p5"][:, :, ::2, ::2])
 
 
 @pytest.mark.parametrize("body", ["V-19-slim-dw-eSE", "V-19-dw-eSE", "V-19-slim-eSE", "V-19-eSE", "V-57-eSE"])
@@ -43,11 +72,11 @@ def test_other_vovnet_bodies_match_reference(dev, body):
     torch.cuda.synchronize()
     for k in ("stage3", "stage4", "stage5"):
         assert tuple(out[k].shape) == tuple(g[k].shape)
-        close(out[k], g[k], 1e-4, body + " " + k)
+        close_abs(out[k], g[k], 1e-3, "features " + body + " " + k)
     out = m.backbone(g["x32"].to(dev))
     torch.cuda.synchronize()
     for k in ("p3", "p4", "p5", "p6", "p7"):
-        close(out[k], g[k], 1e-4, body + " " + k)
+        close_abs(out[k], g[k], 1e-3, "features " + body + " " + k)
 
 
 def test_fcos_head_matches_reference(dev, model):
@@ -64,40 +93,65 @@ def test_fcos_head_matches_reference(dev, model):
         head.cls_logits.bias.data -= shift
         head.invalidate_packed()
     for l in range(5):
-        close(lg[l], g["logits"][l], 1e-3, "logits")
-        close(reg[l], g["reg"][l], 1e-3, "reg")
-        close(ctr[l], g["ctr"][l], 1e-3, "ctr")
+        close_abs(lg[l], g["logits"][l], 1e-3, "fcos_small logits")
+        close_abs(reg[l], g["reg"][l], 1e-3, "fcos_small reg")
+        close_abs(ctr[l], g["ctr"][l], 1e-3, "fcos_small ctr")
 
 
 def _probe_check(t_nchw, p, tol, what):
     flat = t_nchw.contiguous().reshape(-1).cpu()
     assert tuple(t_nchw.shape) == tuple(p["shape"].tolist()), what
-    close(flat[p["idx"]], p["val"], tol, what + " probe")
-    close(flat.double().mean().float().reshape(1), p["mean"].reshape(1), tol, what + " mean")
+    close_abs(flat[p["idx"]], p["val"], tol, what + " probe")
+    close_abs(flat.double().mean().float().reshape(1), p["mean"].reshape(1), tol, what + " mean")
 
 
-def test_end_to_end_800x1280_batch8_tuned_variants_match_oracle(dev, model):
-    """The benchmark configuration itself (8 x 3x800x1280 with the shipped variant table, i.e. the Winograd / N-split kernels
-    bench.py times) against the oracle: labels and ROI locations exact, masks within 1e-3."""
+def _check_against_reference_image(inst, r, what, order_tol):
+    """One image's Instances against the reference's tuple for it: the same detections, labels and ROI locations exact (order up to
+    `order_tol` of score, see match_detections; 0 = identical order), scores / masks / mask scores within 1e-3 absolute."""
+    assert len(inst) == r["scores"].shape[0], (what, len(inst), r["scores"].shape[0])
+    if order_tol > 0:
+        pg = match_detections(r["scores"], r["classes"], r["locations"], inst.scores, inst.pred_classes, inst.locations, tol=order_tol).to(inst.scores.device)
+    else:
+        pg = torch.arange(len(inst), device=inst.scores.device)
+    assert torch.equal(inst.pred_classes[pg].cpu(), r["classes"]), what + ": labels differ"
+    assert torch.equal(inst.locations[pg].cpu(), r["locations"]), what + ": ROI locations differ"
+    close(inst.pred_boxes.tensor[pg], r["boxes"], 2e-5, "e2e boxes (pixels)")   # reg (1e-3 abs, probed) x stride
+    close_abs(inst.scores[pg], r["scores"], 1e-3, "e2e scores")
+    close_abs(inst.pred_masks[pg], r["pred_masks"], 1e-3, "e2e pred_masks")
+    close_abs(inst.mask_scores[pg], r["mask_scores"], 1e-3, "e2e mask_scores")
+    return pg
+
+
+def test_end_to_end_800x1280_batch8_tuned_variants_match_reference(dev, model):
+    """The benchmark configuration itself (8 x 3x800x1280 with the shipped variant table, i.e. the kernels bench.py times) against
+    what the REFERENCE's own modules produced for all eight images (tests/golden/make_golden_bench8.py, tester.py:94-104 call
+    order): labels and ROI locations exact on every image, feature / logit probes, scores, masks and mask scores within 1e-3
+    absolute, candidate counts within the handful of scores that straddle 0.05 at fp32 noise."""
     from centermask2_amd import ops, synthetic as S
-    from oracle import centermask_oracle as O
     from .helpers import load_shipped_variant_table
+    g = golden("e2e_bench8_800x1280")
+    B = int(g["num_images"])
     n_loaded = load_shipped_variant_table()
     try:
-        x = S.make_synthetic_images(8, 800, 1280, seed0=1234)
-        sizes = [(800, 1280)] * 8
-        out = model.inference_padded(x.to(dev), sizes)
+        x = S.make_synthetic_images(B, 800, 1280, seed0=int(g["image_seed0"])).to(dev)
+        sizes = [(800, 1280)] * B
+        out = model.inference_padded(x, sizes)
+        feats = model.backbone(x)
+        lg, reg, ctr, _ = model.proposal_generator.fcos_head([feats[k] for k in ("p3", "p4", "p5", "p6", "p7")])
         torch.cuda.synchronize()
         res = model.results_from_padded(out, sizes)
-        sd = S.make_synthetic_state_dict("V-39-eSE", 0)
-        for i in (0, 5):                         # two of the eight images on the CPU oracle (a few seconds each)
-            want = O.centermask_inference(sd, x[i:i + 1], sizes[:1])[0]
-            assert torch.equal(res[i].pred_classes.cpu(), want["classes"]), "labels differ"
-            assert torch.equal(res[i].locations.cpu(), want["locations"]), "ROI locations differ"
-            close(res[i].pred_boxes.tensor, want["boxes"], 2e-5, "boxes")
-            close(res[i].scores, want["scores"], 1e-4, "scores")
-            close(res[i].pred_masks, want["pred_masks"], 1e-3, "masks")
-            close(res[i].mask_scores, want["mask_scores"], 1e-3, "mask_scores")
+        cand = out["cand_counts"].cpu().tolist()
+        for i in range(B):
+            r = g["img{}".format(i)]
+            for k in ("p3", "p4", "p5", "p6", "p7"):
+                _probe_check(feats[k][i:i + 1], r[k], 1e-3, "bench8 " + k)
+            for l in range(5):
+                _probe_check(lg[l][i:i + 1], r["logits{}".format(l)], 1e-3, "bench8 logits")
+                _probe_check(reg[l][i:i + 1], r["reg{}".format(l)], 1e-3, "bench8 reg")
+                _probe_check(ctr[l][i:i + 1], r["ctr{}".format(l)], 1e-3, "bench8 ctr")
+            # a candidate is sigmoid(logit) > 0.05 (fcos_outputs.py:412): a logit within fp32 noise of the threshold may fall on either side
+            assert abs(cand[i] - int(r["num_candidates"])) <= 4, (i, cand[i], int(r["num_candidates"]))
+            _check_against_reference_image(res[i], r, "bench8 image {}".format(i), ORDER_TOL)
     finally:
         ops._TUNED.clear()
     assert n_loaded >= 0
@@ -123,16 +177,7 @@ def test_end_to_end_800x1280_matches_reference(dev, model):
     torch.cuda.synchronize()
     for i in range(2):
         r, inst = g["img{}".format(i)], res[i]
-        assert len(inst) == r["scores"].shape[0]
-        # the same detections, labels and locations exact; their ORDER may differ only between scores closer than 1e-5 (the fixture's
-        # detections 8 and 9 of image 0 are 2.2e-6 apart — below the network's own fp32 noise; see match_detections)
-        pg = match_detections(r["scores"], r["classes"], r["locations"], inst.scores, inst.pred_classes, inst.locations, tol=1e-5).to(dev)
-        assert torch.equal(inst.pred_classes[pg].cpu(), r["classes"]), "labels differ"
-        assert torch.equal(inst.locations[pg].cpu(), r["locations"]), "ROI locations differ"
-        close(inst.pred_boxes.tensor[pg], r["boxes"], 2e-5, "boxes")   # pixels: reg (1e-3 bar, checked above) x stride x scale
-        close(inst.scores[pg], r["scores"], 1e-4, "scores")
-        close(inst.pred_masks[pg], r["pred_masks"], 1e-3, "pred_masks")
-        close(inst.mask_scores[pg], r["mask_scores"], 1e-3, "mask_scores")
+        _check_against_reference_image(inst, r, "e2e image {}".format(i), ORDER_TOL)
         assert inst.pred_classes.dtype == torch.int64 and tuple(inst.pred_masks.shape[1:]) == (1, 28, 28)
     t = model.forward_tensor(x[:1], hw=[(800, 1280)])
     assert [tuple(v.shape[1:]) for v in t] == [(2,), (), (4,), (), (1, 28, 28), ()]
@@ -147,7 +192,7 @@ def test_v99_small_image_backbone(dev):
     feats = model.backbone(x.to(dev))
     ref = O.backbone_forward(sd, x, "V-99-eSE")
     for k in ("p3", "p4", "p5", "p6", "p7"):
-        close(feats[k], ref[k], 1e-3, "V-99 " + k)
+        close_abs(feats[k], ref[k], 1e-3, "V-99 features " + k)
 
 
 def test_config5_v99_batch8_800x1280(dev):
@@ -190,7 +235,7 @@ def test_config5_v99_batch8_800x1280(dev):
             pg = match_detections(want["scores"], want["classes"], want["locations"], inst.scores, inst.pred_classes, inst.locations).to(dev)
             assert torch.equal(inst.pred_classes[pg].cpu(), want["classes"]) and torch.equal(inst.locations[pg].cpu(), want["locations"])
             close(inst.pred_boxes.tensor[pg], want["boxes"], 2e-5, "boxes")
-            close(inst.scores[pg], want["scores"], 1e-4, "scores")
+            close_abs(inst.scores[pg], want["scores"], 1e-4, "V-99 scores")
             # mask branch on the oracle's boxes (reference API: center_heads.py:413-444): every ROI compared, none excluded
             given = Instances((800, 1280))
             given.pred_boxes = Boxes(want["boxes"].to(dev))
@@ -199,11 +244,11 @@ def test_config5_v99_batch8_800x1280(dev):
             fi = {k: v[i:i + 1] for k, v in feats.items()}
             got = model.roi_heads.forward_with_given_boxes(fi, [given])[0]
             torch.cuda.synchronize()
-            close(got.pred_masks, want["pred_masks"], 1e-3, "pred_masks on the oracle's boxes")
-            close(got.mask_scores, want["mask_scores"], 1e-3, "mask_scores on the oracle's boxes")
+            close_abs(got.pred_masks, want["pred_masks"], 1e-3, "V-99 pred_masks on the oracle's boxes")
+            close_abs(got.mask_scores, want["mask_scores"], 1e-3, "V-99 mask_scores on the oracle's boxes")
             if i == 0:
-                close(got.pred_masks, refs[0]["pred_masks"][pr], 1e-3, "pred_masks vs the reference fixture")
-                close(got.mask_scores, refs[0]["mask_scores"][pr], 1e-3, "mask_scores vs the reference fixture")
+                close_abs(got.pred_masks, refs[0]["pred_masks"][pr], 1e-3, "V-99 pred_masks vs the reference fixture")
+                close_abs(got.mask_scores, refs[0]["mask_scores"][pr], 1e-3, "V-99 mask_scores vs the reference fixture")
     finally:
         ops._TUNED.clear()
         ops._TUNED.update(saved)
@@ -310,4 +355,4 @@ def test_thresh_with_ctr_model_matches_oracle(dev):
     k = int(det["counts"][0])
     assert k == want["scores"].shape[0] and k > 64
     assert torch.equal(det["cls"][0, :k].cpu(), want["classes"]) and torch.equal(det["loc"][0, :k].cpu(), want["locations"])
-    close(det["score"][0, :k], want["scores"], 1e-4, "scores")
+    close_abs(det["score"][0, :k], want["scores"], 1e-4, "thresh_with_ctr scores")
