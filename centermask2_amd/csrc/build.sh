@@ -8,7 +8,7 @@ OBJS=""
 mkdir -p build
 for s in $SRCS; do
   o=build/${s%.hip}.o
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ cmk_common.hpp -nt "$o" ] || [ conv_args.hpp -nt "$o" ] || [ ../../include/cmk.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ cmk_common.hpp -nt "$o" ] || [ conv_args.hpp -nt "$o" ] || [ wino6_common.hpp -nt "$o" ] || [ ../../include/cmk.h -nt "$o" ]; then
     echo "hipcc $s"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" ${CMK_HIPCC_FLAGS}
   fi

@@ -56,6 +56,8 @@ struct DeviceOnce {
 
 // conv_wino6.hip: fused Winograd F(4x4,3x3)
 int launch_wino6(ConvArgs& a, int geo, hipStream_t st);
+// conv_wino6s.hip: the same, 64 couts per workgroup from one frequency image shared through LDS (one 8-wave workgroup per CU)
+int launch_wino6s(ConvArgs& a, int geo, hipStream_t st);
 // conv_pw.hip: 1x1 conv as a GEMM with the weights fetched straight into registers; mt = 4 | 2 accumulator rows per wave
 int launch_pw(ConvArgs& a, int mt, hipStream_t st);
 

@@ -976,6 +976,7 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         a.w = d->w_wino6;
         a.ws = d->splitk_ws;          // instrumented builds (W6_TRACE) only: a stamp buffer; unused otherwise
         if (d->tune_wn != 1 && d->tune_wn != 2) return fail(CMK_EINVAL, "conv: tune_wm 6 takes tune_wn 1 (12x40 map tiles) or 2 (pairs of RoI maps up to 16x14)%s", "");
+        if (d->tune_sc == 64) return launch_wino6s(a, d->tune_wn == 2 ? 1 : 0, st);      // 64 couts per workgroup, shared frequency image
         return launch_wino6(a, d->tune_wn == 2 ? 1 : 0, st);
     }
     a.ksplit = d->splitk > 1 ? d->splitk : 1;

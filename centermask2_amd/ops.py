@@ -234,6 +234,8 @@ def _variant_on_menu(tv) -> bool:
     """(wm, sc, wn[, splitk]) names a kernel this library has (older tables may carry variants that were removed since)."""
     wm, sc, wn = tv[:3]
     sk = tv[3] if len(tv) > 3 else 1
+    if wm == 6 and sc == 64:          # F(4x4,3x3), shared-V form (conv_wino6s.hip)
+        return wn in (1, 2) and sk == 1
     return (wm in (1, 2, 5, 6, 7, 8, 9) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
 
 
@@ -297,6 +299,7 @@ def _tune(descs, n, key) -> None:
     if ALLOW_WINOGRAD:
         cands += [(5, 16, 2, 1)]                  # fused Winograd F(2x2,3x3)
         cands += [(6, 16, 1, 1), (6, 16, 2, 1)]   # fused Winograd F(4x4,3x3): map tiles / pairs of RoI maps (the library rejects what does not apply)
+        cands += [(6, 64, 1, 1), (6, 64, 2, 1)]   # ... its shared-V form: 64 couts per workgroup from one frequency image (conv_wino6s.hip)
     for tv in cands:
         ws = _set_variant(descs, n, tv)
         if run() != 0:
@@ -755,7 +758,7 @@ def kernel_source_hash() -> str:
     import os
     h = hashlib.sha1()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-    for f in ("conv_args.hpp", "conv_igemm.hip", "conv_wino6.hip", "conv_pw.hip"):
+    for f in ("conv_args.hpp", "wino6_common.hpp", "conv_igemm.hip", "conv_wino6.hip", "conv_wino6s.hip", "conv_pw.hip"):
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:12]
 

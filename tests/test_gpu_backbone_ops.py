@@ -398,8 +398,14 @@ def test_conv_winograd6_variant(dev, case):
     rc, y = _run_variant(dev, x, wt, scale, shift, (6, 16, 1))
     assert rc == 0
     _close(y.nchw(), ref)
-    rc, y = _run_variant(dev, x, wt, scale, shift, (6, 16, 1))          # a second, warm launch agrees bit for bit with the first
+    rc, y2 = _run_variant(dev, x, wt, scale, shift, (6, 16, 1))         # a second, warm launch agrees bit for bit with the first
+    assert rc == 0 and torch.equal(y.t, y2.t)
+    # the shared-V form (tune_sc 64: 64 couts per workgroup from one frequency image in LDS, conv_wino6s.hip) does the same arithmetic
+    # in the same order: identical bits, also where the number of 32-cout tiles is odd (the idle wave group) and on ragged edges
+    rc, y3 = _run_variant(dev, x, wt, scale, shift, (6, 64, 1))
     assert rc == 0
+    _close(y3.nchw(), ref)
+    assert torch.equal(y.t, y3.t), "conv_wino6s differs from conv_wino6"
 
 
 @pytest.mark.parametrize("case", [(6, 14, 14, 256, 80), (5, 14, 14, 272, 256), (3, 16, 14, 32, 64), (2, 7, 7, 64, 32), (1, 14, 14, 64, 33)])
@@ -415,12 +421,18 @@ def test_conv_winograd6_roi_pair_geometry(dev, case):
     rc, y = _run_variant(dev, x, wt, scale, shift, (6, 16, 2))
     assert rc == 0
     _close(y.nchw(), ref)
+    rc, y3 = _run_variant(dev, x, wt, scale, shift, (6, 64, 2))         # the shared-V form of the same geometry: identical bits
+    assert rc == 0
+    _close(y3.nchw(), ref)
+    assert torch.equal(y.t, y3.t), "conv_wino6s differs from conv_wino6"
     # maps wider than 14 columns are refused by this geometry
-    rc, _ = _run_variant(dev, _rand((2, 32, 14, 15), 95), _rand((32, 32, 3, 3), 96, 0.05), None, None, (6, 16, 2))
-    assert rc != 0
+    for sc in (16, 64):
+        rc, _ = _run_variant(dev, _rand((2, 32, 14, 15), 95), _rand((32, 32, 3, 3), 96, 0.05), None, None, (6, sc, 2))
+        assert rc != 0
 
 
-def test_conv_winograd6_channel_views(dev):
+@pytest.mark.parametrize("sc", [16, 64])
+def test_conv_winograd6_channel_views(dev, sc):
     """tune_wm 6 reading a channel slice of a wider buffer (an OSA concat buffer) and writing into a slice of another; partial ReLU."""
     import ctypes
     from centermask2_amd import _lib
@@ -431,7 +443,7 @@ def test_conv_winograd6_channel_views(dev):
     pc = ops.PackedConv(wt, None, _rand((cout,), 8, 0.1), dev)
     d = (_lib.ConvDesc * 1)()
     ops._fill_desc(d[0], View(big, 32, cin), pc, View(out, 16, cout), False, 4, None, False, False)
-    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 6, 16, 1
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 6, sc, 1
     _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "wino6 views")
     torch.cuda.synchronize()
     ref = F.conv2d(big[..., 32:96].permute(0, 3, 1, 2).cpu(), wt, pc.shift.cpu(), padding=1)
@@ -518,7 +530,7 @@ def test_conv_split_k_rejects_bad_requests(dev, cmk_lib):
     del ws
 
 
-@pytest.mark.parametrize("variant", [(0, 0, 0), (5, 16, 2), (6, 16, 1), (1, 16, 1)])
+@pytest.mark.parametrize("variant", [(0, 0, 0), (5, 16, 2), (6, 16, 1), (6, 64, 1), (1, 16, 1)])
 def test_conv_fused_groupnorm_relu_input(dev, variant):
     """conv(relu(GroupNorm(x))) with the GN apply fused into the conv's input staging (direct kernels and Winograd form 6)."""
     import ctypes
@@ -544,11 +556,12 @@ def test_conv_fused_groupnorm_relu_input(dev, variant):
     assert _lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
 
 
-@pytest.mark.parametrize("form", [5, 6])
+@pytest.mark.parametrize("form", [5, 6, 664])
 @pytest.mark.parametrize("cout,groups", [(256, 32), (64, 32), (96, 3)])
 def test_conv_with_fused_groupnorm_statistics(dev, cout, groups, form, monkeypatch):
-    """The Winograd epilogues' {sum, sumsq} records -> the same per-(image, channel) affine as a pass over the output."""
-    monkeypatch.setattr(ops, "FORCE_VARIANT", (form, 16, 2 if form == 5 else 1))
+    """The Winograd epilogues' {sum, sumsq} records -> the same per-(image, channel) affine as a pass over the output
+    (664: the shared-V form of F(4x4), tune_wm 6 / tune_sc 64)."""
+    monkeypatch.setattr(ops, "FORCE_VARIANT", (6, 64, 1) if form == 664 else (form, 16, 2 if form == 5 else 1))
     g = torch.Generator().manual_seed(21)
     shapes = [(2, 20, 36), (2, 9, 17), (2, 5, 3)]
     cin = 64

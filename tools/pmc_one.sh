@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes of ONE conv shape with a forced variant: tools/pmc_one.sh <tag> H W Cin Cout wm  (on the GPU box, from the repo root)
+# PMC passes of ONE conv shape with a forced variant: tools/pmc_one.sh <tag> H W Cin Cout wm sc wn  (on the GPU box, from the repo root)
+# (counters in their own runs, --kernel-trace only, as the MI355X guide prescribes)
 TAG=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 i=0
