@@ -190,13 +190,22 @@ def build_maskiou_head(cfg, input_shape):
     return ROI_MASKIOU_HEAD_REGISTRY.get(cfg.MODEL.ROI_MASKIOU_HEAD.NAME)(cfg, input_shape)
 
 
+def lazy_batch_of(instances: List[Instances]):
+    """The LazyBatch behind `instances` if they are exactly the (unmodified) list one FCOS.forward call returned, else None."""
+    first = instances[0]
+    if not hasattr(first, "lazy_batch"):
+        return None
+    batch = first.lazy_batch()[0]
+    if batch is None or len(instances) != len(batch.image_sizes):
+        return None
+    for i, it in enumerate(instances):
+        if not hasattr(it, "lazy_batch") or it.lazy_batch()[0] is not batch or it.lazy_batch()[1] != i:
+            return None
+    return batch
+
+
 def padded_from_instances(instances: List[Instances], device) -> Tuple[dict, int]:
     """Build the padded [image][K] device buffers from foreign Instances (pred_boxes, pred_classes[, scores])."""
-    first = instances[0]
-    if getattr(first, "_cmk_padded", None) is not None and all(
-            getattr(it, "_cmk_padded", (None, -1))[0] is first._cmk_padded[0] and it._cmk_padded[1] == i for i, it in enumerate(instances)):
-        det = first._cmk_padded[0]
-        return det, det["box"].shape[1]
     n = len(instances)
     k = max(1, max(len(it) for it in instances))
     det = dict(box=torch.zeros((n, k, 4), dtype=torch.float32, device=device), score=torch.zeros((n, k), dtype=torch.float32, device=device),
@@ -313,11 +322,21 @@ class CenterROIHeads(HipModule):
         """center_heads.py:413-444: adds pred_masks and mask_scores in place; with zero boxes overall the reference returns
         without mask_scores (center_heads.py:513-514) — here an empty tensor is attached instead."""
         assert not self.training
-        assert instances[0].has("pred_boxes") and instances[0].has("pred_classes")
         dev = next(iter(features.values())).device
-        det, k = padded_from_instances(instances, dev)
+        batch = lazy_batch_of(instances)
+        if batch is not None and batch.counts is None:
+            # the proposals are FCOS's own, still on the device and unread: enqueue the ROI heads on the padded buffers and leave the
+            # result with the batch — the Instances gain pred_masks / mask_scores when their fields are first read (no host sync here)
+            sizes = [it.image_size for it in instances]
+            out = self.forward_padded(features, batch.det, sizes)
+            batch.attach_roi(out, lambda det2: self.forward_padded(features, det2, sizes))
+            return instances
+        assert instances[0].has("pred_boxes") and instances[0].has("pred_classes")
+        if batch is not None:
+            det, k = batch.det, batch.det["box"].shape[1]
+        else:
+            det, k = padded_from_instances(instances, dev)
         out = self.forward_padded(features, det, [it.image_size for it in instances])
-        s2 = 2 * self.mask_pooler.output_size if self.mask_on else 28
         for i, it in enumerate(instances):
             m = len(it)
             if self.mask_on:

@@ -200,18 +200,88 @@ class FCOS(HipModule):
         return det2
 
     def forward(self, images, features, gt_instances=None):
-        """fcos.py:61-118 (inference branch): -> (list[Instances], {}).  `images` needs len() and .image_sizes."""
+        """fcos.py:61-118 (inference branch): -> (list[Instances], {}).  `images` needs len() and .image_sizes.
+        Nothing is read back here: the Instances are LAZY (LazyInstances below) — their fields are sliced out of the padded device
+        buffers on first access, which is also where the candidate-overflow check happens — so a caller that hands them straight to
+        CenterROIHeads (tester.py:57-66, modified_class.py:35-38) keeps the GPU fed across the two plugins."""
         if self.training:
             raise NotImplementedError("training is out of scope of the MI355X inference path")
         det, _ = self.forward_padded(features)
-        det = self.resolve_overflow(det)
-        return instances_from_padded(det, images.image_sizes), {}
+        batch = LazyBatch(det, images.image_sizes, self)
+        return [LazyInstances(tuple(hw), batch, i) for i, hw in enumerate(images.image_sizes)], {}
+
+
+class LazyBatch:
+    """The padded device buffers behind a list of LazyInstances (one FCOS call) and, once CenterROIHeads has run on them, the ROI
+    outputs.  resolve() is the single host synchronisation: it reads the candidate counts, re-runs select + NMS (+ the ROI heads)
+    with a larger capacity if an image overflowed — the reference is unbounded (fcos_outputs.py:444-449) — and reads the per-image
+    detection counts."""
+
+    def __init__(self, det: dict, image_sizes, fcos):
+        self.det, self.image_sizes, self.fcos = det, [tuple(hw) for hw in image_sizes], fcos
+        self.out = None          # ROI-head outputs over the same padded buffers (pred_masks, mask_scores), if any
+        self.redo = None         # det -> ROI-head outputs, for the overflow re-run
+        self.counts = None       # per-image detection counts on the host, once resolved
+
+    def attach_roi(self, out: dict, redo) -> None:
+        self.out, self.redo = out, redo
+
+    def resolve(self) -> None:
+        if self.counts is not None:
+            return
+        det = self.det
+        if "cand_capacity" in det and int(det["cand_counts"].max()) > det["cand_capacity"]:
+            det = self.fcos.resolve_overflow(det)
+            self.det = det
+            if self.out is not None:
+                self.out = self.redo(det)
+        self.counts = det["counts"].cpu().tolist()
+
+    def fields_of(self, i: int) -> dict:
+        self.resolve()
+        det, k = self.det, self.counts[i]
+        f = {"pred_boxes": Boxes(det["box"][i, :k]), "scores": det["score"][i, :k], "pred_classes": det["cls"][i, :k],
+             "locations": det["loc"][i, :k]}
+        if self.out is not None:
+            for name in ("pred_masks", "mask_scores"):
+                if name in self.out:
+                    f[name] = self.out[name][i, :k]
+        return f
+
+
+class LazyInstances(Instances):
+    """Instances (fields of fcos_outputs.py:458-462) whose fields are sliced out of the batch's padded device buffers on first access.
+    Behaves like Instances in every other respect; indexing / .to() return plain Instances."""
+
+    def __init__(self, image_size, batch: LazyBatch, index: int):
+        object.__setattr__(self, "_image_size", image_size)
+        object.__setattr__(self, "_cmk_lazy", (batch, index))
+        object.__setattr__(self, "_store", None)
+
+    @property
+    def _fields(self):
+        st = self.__dict__["_store"]
+        if st is None:
+            batch, i = self.__dict__["_cmk_lazy"]
+            st = batch.fields_of(i)
+            object.__setattr__(self, "_store", st)
+        return st
+
+    def set(self, name: str, value) -> None:
+        if name in ("pred_boxes", "pred_classes", "scores", "locations"):
+            _ = self._fields                                     # materialise first, then the caller's value replaces ours ...
+            object.__setattr__(self, "_cmk_lazy", (None, -1))    # ... and the padded buffers no longer describe this object
+        Instances.set(self, name, value)
+
+    def lazy_batch(self):
+        """(LazyBatch, index) while the padded buffers still describe this object, else (None, -1)."""
+        return self.__dict__["_cmk_lazy"]
 
 
 def instances_from_padded(det: dict, image_sizes) -> List[Instances]:
     """One host sync: read the per-image counts, slice the padded device buffers into Instances
-    (fields of fcos_outputs.py:458-462).  The padded buffers ride along for CenterROIHeads.  Overflow must have been resolved
-    (FCOS.resolve_overflow) — a truncated candidate set is refused here rather than handed on."""
+    (fields of fcos_outputs.py:458-462).  Overflow must have been resolved (FCOS.resolve_overflow) — a truncated candidate set is
+    refused here rather than handed on."""
     counts = det["counts"].cpu().tolist()
     if "cand_capacity" in det and int(det["cand_counts"].max()) > det["cand_capacity"]:
         raise RuntimeError("FCOS candidates overflowed the capacity {}: call FCOS.resolve_overflow(det) first".format(det["cand_capacity"]))
@@ -222,6 +292,5 @@ def instances_from_padded(det: dict, image_sizes) -> List[Instances]:
         inst.scores = det["score"][i, :k]
         inst.pred_classes = det["cls"][i, :k]
         inst.locations = det["loc"][i, :k]
-        inst._cmk_padded = (det, i)
         out.append(inst)
     return out

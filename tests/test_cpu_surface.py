@@ -226,6 +226,55 @@ def test_all_gather_world_size_2_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
 
 
+_BENCH_GLOO_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import bench
+from centermask2_amd.dist import pack_records, record_width, unpack_records
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cpu")
+B, K = 3, 4
+g = torch.Generator().manual_seed(100 + rank)
+def fake_out(r):
+    gg = torch.Generator().manual_seed(100 + r)
+    return dict(box=torch.rand((B, K, 4), generator=gg), score=torch.rand((B, K), generator=gg), mask_scores=torch.rand((B, K), generator=gg),
+                loc=torch.rand((B, K, 2), generator=gg), cls=torch.randint(0, 80, (B, K), generator=gg), pred_masks=torch.rand((B, K, 1, 28, 28), generator=gg),
+                counts=torch.tensor([K, 1 + r, 0], dtype=torch.int32))
+exchange = bench.RecordExchange(world)
+calls = []
+def step():
+    out = fake_out(rank)
+    rec = pack_records(out)            # the CPU form of the same record layout
+    calls.append(1)
+    return out, exchange(rec)
+elapsed, (out, gathered) = bench.timed_steps(step, 4, 2, world, dev)
+assert len(calls) == 6 and elapsed > 0.0
+assert tuple(gathered.shape) == (world * B, record_width(K))
+for r in range(world):                                   # rank order, every rank's rows intact
+    back = unpack_records(gathered[r * B:(r + 1) * B], K)
+    want = fake_out(r)
+    for key in ("box", "score", "mask_scores", "loc", "cls", "pred_masks", "counts"):
+        assert torch.equal(back[key], want[key] if key not in ("cls",) else want[key].to(torch.int64)), (rank, r, key)
+desc = bench.collective_description(record_width(K), world)
+assert "over 2 ranks" in desc and "'gloo'" in desc, desc
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_bench_exchange_and_timed_region_world_size_2_gloo(tmp_path):
+    """bench.py's own N > 1 code — RecordExchange (all_gather_into_tensor into a buffer allocated once) and timed_steps (barrier + sync on
+    both sides, max over ranks) — driven by two CPU processes over gloo, as `bench.py --gpus 2` drives it over RCCL."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+
+
 def test_average_precision_known_answers():
     from centermask2_amd.evaluation import average_precision, box_iou
     gt = [dict(boxes=torch.tensor([[0., 0., 10., 10.], [20., 20., 40., 40.]]), classes=torch.tensor([1, 2]))]
@@ -290,3 +339,45 @@ def test_device_mismatch_is_refused(monkeypatch):
         ops._need_gpu(FakeCuda1(), "conv2d")
     monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
     ops._need_gpu(FakeCuda1(), "conv2d")                    # same device: accepted
+
+
+def test_lazy_instances_between_the_plugins():
+    """FCOS.forward hands out LazyInstances over its padded device buffers; CenterROIHeads attaches its outputs to the same batch; the
+    first field access is the single host sync (counts, overflow re-run).  Plain tensors stand in for the device buffers here."""
+    from centermask2_amd.modeling.centermask.center_heads import lazy_batch_of
+    from centermask2_amd.modeling.fcos.fcos import LazyBatch, LazyInstances
+    from centermask2_amd.structures import Boxes, Instances
+    n, k = 2, 4
+    det = dict(box=torch.arange(n * k * 4, dtype=torch.float32).reshape(n, k, 4), score=torch.rand(n, k), cls=torch.arange(n * k).reshape(n, k),
+               loc=torch.rand(n, k, 2), counts=torch.tensor([3, 0], dtype=torch.int32), cand_counts=torch.tensor([10, 2], dtype=torch.int32), cand_capacity=16)
+
+    class FakeFcos:
+        calls = 0
+
+        def resolve_overflow(self, d):
+            FakeFcos.calls += 1
+            d2 = dict(d)
+            d2["cand_capacity"] = 64
+            d2["counts"] = torch.tensor([4, 1], dtype=torch.int32)
+            return d2
+
+    batch = LazyBatch(det, [(8, 9), (8, 9)], FakeFcos())
+    insts = [LazyInstances((8, 9), batch, i) for i in range(n)]
+    assert isinstance(insts[0], Instances) and insts[0].image_size == (8, 9) and batch.counts is None
+    assert lazy_batch_of(insts) is batch and lazy_batch_of(insts[::-1]) is None and lazy_batch_of(insts[:1]) is None
+    batch.attach_roi(dict(det, pred_masks=torch.rand(n, k, 1, 28, 28), mask_scores=torch.rand(n, k)), lambda d2: None)
+    assert batch.counts is None                                         # still nothing read
+    assert len(insts[0]) == 3 and len(insts[1]) == 0 and batch.counts == [3, 0] and FakeFcos.calls == 0
+    assert isinstance(insts[0].pred_boxes, Boxes) and torch.equal(insts[0].pred_boxes.tensor, det["box"][0, :3])
+    assert tuple(insts[0].pred_masks.shape) == (3, 1, 28, 28) and tuple(insts[1].pred_masks.shape) == (0, 1, 28, 28)
+    assert insts[0].has("mask_scores") and tuple(insts[1].mask_scores.shape) == (0,)
+    assert type(insts[0][0:2]) is Instances and len(insts[0][0:2]) == 2
+    insts[0].pred_classes = torch.zeros(3, dtype=torch.int64)            # a caller's own value: the padded buffers no longer describe it
+    assert lazy_batch_of(insts) is None and torch.equal(insts[0].pred_classes, torch.zeros(3, dtype=torch.int64))
+    # overflow: the capacity was too small -> resolve() re-runs the tail (and the ROI heads) through the callbacks
+    det2 = dict(det, cand_counts=torch.tensor([100, 2], dtype=torch.int32))
+    redo = []
+    b2 = LazyBatch(det2, [(8, 9), (8, 9)], FakeFcos())
+    b2.attach_roi(dict(det2), lambda d2: redo.append(1) or dict(d2, pred_masks=torch.zeros(n, k, 1, 28, 28)))
+    i2 = [LazyInstances((8, 9), b2, i) for i in range(n)]
+    assert len(i2[0]) == 4 and len(i2[1]) == 1 and FakeFcos.calls == 1 and redo == [1] and i2[1].has("pred_masks")
