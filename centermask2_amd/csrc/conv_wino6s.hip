@@ -31,6 +31,9 @@
 #ifndef W6S_FENCE
 #define W6S_FENCE __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef W6S_PRIO
+#define W6S_PRIO 1    // wave priority during the transform phase (0..3); measured 1.8 % faster than 0 on the model's map shapes, 2 and 3 the same
+#endif
 #ifndef W6S_ABL
 #define W6S_ABL 0     // timing ablations (tools/ab; results are wrong with any set): 1 no pass 1, 2 no halo loads, 4 no weight loads, 8 no pass 2,
 #endif                //   16 no MFMAs, 32 no barrier, 64 no V reads; finer: 128 no V stores (pass 2), 256 no W stores (pass 1), 512 no pass-2 VALU,
@@ -428,6 +431,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6s_kernel(const ConvArgs a) {
         constexpr int vnxt2 = (1 - par) * VS * 2;            // f32x2 units
         constexpr int wrd2 = (1 - par) * WB * 2;
         constexpr int wwr = par * WB * 2;
+#if W6S_PRIO
+        __builtin_amdgcn_s_setprio(W6S_PRIO);             // the transform phase competes with the SIMD partner's MFMA stream for issue slots
+#endif
 #if !(W6S_ABL & 8)
 #ifdef W6S_X64
         X5 x0 = rd5(xa + wrd2, x3 + wrd2);
@@ -451,6 +457,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6s_kernel(const ConvArgs a) {
         taskXq(xq, reinterpret_cast<f32x4*>(vX + vnxt2));
 #endif
         taskY(xy, vY + vnxt2);
+#endif
+#if W6S_PRIO
+        __builtin_amdgcn_s_setprio(0);
 #endif
     };
     // M(cw): the 36 MFMAs of chunk cw on V(cw) (pa, pb: the wave's row-A / row-B operand pointers into that V buffer), weights of chunk cw + 1 requested
