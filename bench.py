@@ -26,7 +26,7 @@ import torch.distributed as dist
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
-PROFILE_ROUND = "r02"            # prefix of the PMC summaries under profiles/ this bench quotes
+PROFILE_ROUND = "r03"            # prefix of the PMC summaries under profiles/ this bench quotes
 
 
 def build(conv_body, device):

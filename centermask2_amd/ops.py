@@ -772,6 +772,7 @@ def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) 
     if wm == 5:      # workgroup = 8x16 outputs x 64 couts: 256 MFMAs of 4096 FLOP per 16-channel chunk
         return float(sum(n * cd(h, 8) * cd(w, 16) for n, h, w in shapes) * cd(cout, 64) * (cin_pad // 16) * 256 * 4096)
     if wm == 6:      # workgroup = 12x40 outputs (wn 1) or two whole RoI maps (wn 2) x 32 couts: 144 MFMAs per 8-channel chunk
+        # (the shared-V form, sc 64, runs two such cout tiles per workgroup; a wave group without a tile issues no MFMAs: the same count)
         wgs = sum(cd(n, 2) for n, h, w in shapes) if wn == 2 else sum(n * cd(h, 12) * cd(w, 40) for n, h, w in shapes)
         return float(wgs * cd(cout, 32) * (cin_pad // 8) * 144 * 4096)
     cout_pad = _lib.load().cmk_conv_cout_pad(cout)
@@ -796,7 +797,7 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False) -> str:
     if tv[0] == 5:
         return "conv_wino4r_kernel<{}>".format("true" if aff else "false")
     if tv[0] == 6:
-        return "conv_wino6_kernel<{}, {}>".format("true" if aff else "false", 1 if tv[2] == 2 else 0)
+        return "conv_wino6{}_kernel<{}, {}>".format("s" if tv[1] == 64 else "", "true" if aff else "false", 1 if tv[2] == 2 else 0)
     wm, sc, wn = tv[:3]
     sk = "true" if (len(tv) > 3 and tv[3] > 1) else "false"
     if wm == 8:
