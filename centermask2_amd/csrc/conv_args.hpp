@@ -8,7 +8,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PST = 20;      // LDS row pitch in floats: 16 channels + 4 pad
-constexpr int MAXP = 5;      // problems (FPN levels) per launch
+constexpr int MAXP = 10;     // problems per launch: the 5 FPN levels, twice where two convs with different weights share a launch (F(4x4) kernels)
 constexpr int LDS_CU = 160 * 1024;
 
 // workgroups per CU the register budget allows (accumulators: 16 VGPRs per 32x32 tile)
@@ -17,6 +17,7 @@ __host__ __device__ constexpr int occ_of(int wm, int wn, int stride) { return (s
 struct ConvProblem {
     const float* x; float* y; const float* scale; const float* shift;
     const float* in_scale; const float* in_shift;   // optional (N, Cin): x' = relu(x * in_scale + in_shift) while staging (fused GroupNorm+ReLU)
+    const float* w;                                 // F(4x4) kernels: this problem's packed U (problems of one launch may differ in weights); else unused
     int N, H, W, Ho, Wo;
     int tiles_h, tiles_w, tile_begin;
     long total_pix;  // N*Ho*Wo

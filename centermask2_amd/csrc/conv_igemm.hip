@@ -879,6 +879,7 @@ static int validate(const cmk_conv_desc* d) {
 static void fill_problem(ConvProblem& p, const cmk_conv_desc* d) {
     p.x = d->x; p.y = d->y; p.scale = d->scale; p.shift = d->shift;
     p.in_scale = d->in_scale; p.in_shift = d->in_shift;
+    p.w = d->w_wino6;
     p.N = d->N; p.H = d->H; p.W = d->W;
     p.Ho = d->stride == 1 ? d->H : (d->H - 1) / 2 + 1;  // k3 p1 s2: floor((H+2-3)/2)+1
     p.Wo = d->stride == 1 ? d->W : (d->W - 1) / 2 + 1;
@@ -1115,15 +1116,23 @@ extern "C" int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream) {
 extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* stream) {
     using namespace cmk;
     if (!descs || n < 1 || n > MAXP) return fail(CMK_EINVAL, "conv_multi: need 1..%s%ld problems", "", MAXP);
+    bool same_w = true;
     for (int i = 0; i < n; ++i) {
         int rc = validate(&descs[i]);
         if (rc) return rc;
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
-        if (b->w != a->w || b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
+        same_w = same_w && b->w == a->w && b->w_wino == a->w_wino && b->w_wino6 == a->w_wino6;
+        if (b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
-            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || b->w_wino != a->w_wino || b->w_wino6 != a->w_wino6 || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
+            b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
             b->gn_ws != a->gn_ws || b->gn_groups != a->gn_groups || b->splitk > 1 || b->pool_ws)
-            return fail(CMK_EINVAL, "conv_multi: problems must share weights/channels/views and carry no residual%s", "");
+            return fail(CMK_EINVAL, "conv_multi: problems must share channels/views/flags and carry no residual%s", "");
     }
+    // problems with different weights (the cls and the bbox tower of the FCOS head, fcos.py:227-231, in one launch) and more than 5 problems:
+    // the F(4x4) kernels only, which take the packed weights per problem
+    if ((!same_w || n > 5) && (descs[0].tune_wm != 6 || descs[0].tune_wn != 1))
+        return fail(CMK_EINVAL, "conv_multi: different weights per problem / more than 5 problems need tune_wm 6, tune_wn 1 (the F(4x4) map kernels)%s", "");
+    for (int i = 0; i < n; ++i)
+        if (descs[0].tune_wm == 6 && !descs[i].w_wino6) return fail(CMK_EINVAL, "conv_multi: w_wino6 missing%s", "");
     return run(descs, n, stream);
 }

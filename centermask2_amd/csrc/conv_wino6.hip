@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     const f32x4* wB3 = wB + (halfB ? 1 : 3 * G::CK);
     // U image: [chunk][cout tile][wave][9 slots][lane 64][4 floats]; slot k < 6: frequency (rowA, k); k >= 6: (rowB, 3*halfB + k - 6);
     // lane = 32*hh + li holds channels 8*chunk + 4*hh .. +3 of output channel 32*tile + li
-    const float* u_wave = a.w + ((long)by * 4 + wave) * (9 * 256);       // wave-uniform: the loads take it as a scalar base, lane * 16 B as offset
+    const float* u_wave = P.w + ((long)by * 4 + wave) * (9 * 256);       // wave-uniform: the loads take it as a scalar base, lane * 16 B as offset
     const long u_chunk = (long)a.grid_y * (36 * 256);
     const int u_lane_off = lane * 4;
     f32x4 ub[3][3];
@@ -496,7 +496,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
                     for (int j = 0; j < 4; ++j) {
                         const float val = rr ? yv[i][j].y : yv[i][j].x;
                         // ("+s": the pointer is walked between the stores, not computed 16 times up front)
-                        asm volatile("global_store_dword %1, %2, %0" : "+s"(sp) : "v"(voff), "v"(val) : "memory");
+                        // nt: the output is a stream (84 MB per launch at stage 2) that must not push the weights and the halo lines this launch re-reads
+                        // out of L2; measured -2.2 % on the map shapes, +0.4 % end to end (profiles/r03_ablations.txt), sc0 / sc1 nothing
+                        asm volatile("global_store_dword %1, %2, %0 nt" : "+s"(sp) : "v"(voff), "v"(val) : "memory");
                         sp += j == 3 ? rowskip_b : px_b;
                     }
             } else if (tile_ok) {

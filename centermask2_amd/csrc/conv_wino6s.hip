@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6s_kernel(const ConvArgs a) {
     const f32x4* const vA = sV + (g * 6) * 64 + lane;
     const f32x4* const vB = sV + ((4 + (g >> 1)) * 6 + 3 * (g & 1)) * 64 + lane;
     // U image: [chunk][cout tile][g][9 slots][lane 64][4 floats] (ops.pack_wino6_weight)
-    const float* u_wave = a.w + ((long)min(t32, ntiles32 - 1) * 4 + g) * (9 * 256);       // wave-uniform: scalar base, lane * 16 B as offset
+    const float* u_wave = P.w + ((long)min(t32, ntiles32 - 1) * 4 + g) * (9 * 256);       // wave-uniform: scalar base, lane * 16 B as offset
     const long u_chunk = (long)ntiles32 * (36 * 256);
     const int u_lane_off = lane * 4;
     f32x4 ub[9];
@@ -672,7 +672,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6s_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float val = rr ? yv[i][j].y : yv[i][j].x;
-                            asm volatile("global_store_dword %1, %2, %0" : "+s"(sp) : "v"(voff), "v"(val) : "memory");
+                            // nt: the output is a stream (84 MB per launch at stage 2) that must not push the weights and the halo lines this launch re-reads
+                        // out of L2; measured -2.2 % on the map shapes, +0.4 % end to end (profiles/r03_ablations.txt), sc0 / sc1 nothing
+                        asm volatile("global_store_dword %1, %2, %0 nt" : "+s"(sp) : "v"(voff), "v"(val) : "memory");
                             sp += j == 3 ? rowskip_b : px_b;
                         }
                 } else if (tile_ok) {

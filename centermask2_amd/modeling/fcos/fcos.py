@@ -113,6 +113,27 @@ class FCOSHead(HipModule):
                 xs, aff = ops.conv_gn_multi(xs, [pc] * len(xs), gamma, beta, groups, eps, in_affine=aff)
         return xs, aff
 
+    @classmethod
+    def _run_tower_pair(cls, xs: List[View], tower_a, tower_b, aff=None):
+        """The cls and the bbox tower side by side (fcos.py:227-231: same input, same shapes, different weights): conv k of both towers
+        is ONE launch of 2 x levels problems where the F(4x4) kernel runs it (ops.conv_gn_multi_pair) — half the launch ramps and tails;
+        otherwise (other kernels, towers of different depth, no GroupNorm) the towers run one after the other as before."""
+        same = len(tower_a) == len(tower_b) and all(ta[1] is not None and tb[1] is not None and ta[3] == tb[3] and ta[4] == tb[4]
+                                                    for ta, tb in zip(tower_a, tower_b))
+        if not same:
+            a, aa = cls._run_tower(xs, tower_a, aff)
+            b, ba = cls._run_tower(xs, tower_b, aff)
+            return a, aa, b, ba
+        xa, xb, aa, ab = xs, xs, aff, aff
+        for (pca, ga, bea, eps, groups), (pcb, gb, beb, _, _) in zip(tower_a, tower_b):
+            pair = ops.conv_gn_multi_pair(xa, pca, (ga, bea), xb, pcb, (gb, beb), groups, eps, in_affine_a=aa, in_affine_b=ab)
+            if pair is None:
+                xa, aa = ops.conv_gn_multi(xa, [pca] * len(xa), ga, bea, groups, eps, in_affine=aa)
+                xb, ab = ops.conv_gn_multi(xb, [pcb] * len(xb), gb, beb, groups, eps, in_affine=ab)
+            else:
+                (xa, aa), (xb, ab) = pair
+        return xa, aa, xb, ab
+
     def forward_views(self, feats: List[View]):
         """-> (logits[l] (N,H,W,C) NHWC, regctr[l] (N,H,W,5) = [relu(scale_l*bbox_pred) x4, ctrness logit])."""
         P = self.packed()
@@ -120,8 +141,7 @@ class FCOSHead(HipModule):
         out_l, out_r = [], []
         for g0 in range(0, nl, 5):                      # the multi-problem launch takes up to 5 levels
             f, fa = self._run_tower(list(feats[g0:g0 + 5]), P["share"])
-            cls_t, ca = self._run_tower(f, P["cls"], fa)
-            box_t, ba = self._run_tower(f, P["bbox"], fa)
+            cls_t, ca, box_t, ba = self._run_tower_pair(f, P["cls"], P["bbox"], fa)
             out_l += [v.t for v in ops.conv_out_multi(cls_t, [P["cls_logits"]] * len(cls_t), in_affine=ca)]
             out_r += [v.t for v in ops.conv_out_multi(box_t, P["regctr"][g0:g0 + 5], relu_upto=4, in_affine=ba)]       # fcos.py:233-238
         return out_l, out_r

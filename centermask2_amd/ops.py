@@ -194,6 +194,7 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
 
 # ---- tile-variant autotuning (host side; the library itself stays stateless) -----------------------------------
 FUSE_POOL = os.environ.get("CMK_FUSE_POOL", "1") != "0"      # eSE: average-pool partial sums from the aggregation conv's epilogue (A/B switch)
+PAIR_TOWERS = os.environ.get("CMK_PAIR_TOWERS", "1") != "0"  # FCOS head: conv k of the cls and the bbox tower in one launch (A/B switch)
 PACK_WINO6 = True         # pack the F(4x4,3x3) weights too (4x the filter bank per 3x3 stride-1 conv)
 ALLOW_WINOGRAD = True     # let the tuner pick the Winograd F(2x2,3x3) kernel where it is faster (fp32, differs by rounding only)
 FORCE_VARIANT = None      # (wm, sc, wn[, splitk]) for every conv launched through the wrappers below (tests, A/B tools); None = table/tuner/default
@@ -446,6 +447,77 @@ def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Te
                                          _stream()), "cmk_groupnorm_affine_tiles")
     del ws
     return ys, out
+
+
+def conv_gn_multi_pair(xs_a: Sequence[View], pc_a: PackedConv, gn_a, xs_b: Sequence[View], pc_b: PackedConv, gn_b, groups: int = 32, eps: float = 1e-5,
+                       in_affine_a=None, in_affine_b=None):
+    """Two tower convs with DIFFERENT weights (the cls and the bbox tower of the FCOS head, fcos.py:227-231) over the same level shapes in
+    ONE launch of up to 10 problems — half the launch ramps and tails of two launches — each followed by its own GroupNorm statistics
+    (gn_x = (gamma, beta)).  Only the F(4x4) map kernels take per-problem weights: returns None when the measured / default variant of this
+    problem is another kernel or the fused statistics do not apply (the caller then runs the two towers separately).
+    Returns ((ys_a, affine_a), (ys_b, affine_b)) like two conv_gn_multi calls."""
+    lib = _lib.load()
+    na, nb = len(xs_a), len(xs_b)
+    n = na + nb
+    if not PAIR_TOWERS:
+        return None
+    if na != nb or n > 10 or pc_a.cout != pc_b.cout or pc_a.cin_pad != pc_b.cin_pad or pc_a.w_wino6 is None or pc_b.w_wino6 is None:
+        return None
+    if (in_affine_a is None) != (in_affine_b is None) or any(tuple(a.t.shape) != tuple(b.t.shape) for a, b in zip(xs_a, xs_b)):
+        return None
+    cpg = pc_a.cout // groups if groups > 0 and pc_a.cout % groups == 0 else 0
+    if not (0 < cpg <= 32 and (cpg & (cpg - 1)) == 0) or any(x.t.shape[0] != xs_a[0].t.shape[0] for x in xs_a):
+        return None
+    xs, pcs = list(xs_a) + list(xs_b), [pc_a] * na + [pc_b] * nb
+    affs = (list(in_affine_a) + list(in_affine_b)) if in_affine_a is not None else None
+    ys = [View(torch.empty((x.t.shape[0], x.t.shape[1], x.t.shape[2], pc_a.cout), dtype=torch.float32, device=x.t.device)) for x in xs]
+    descs = (ConvDesc * n)()
+    for i in range(n):
+        _fill_desc(descs[i], xs[i], pcs[i], ys[i], False, None, None, False, False, affs[i] if affs is not None else None)
+    # the variant measured for ONE tower's launch (the table is keyed by the 5 level shapes) decides; the 10-problem launch has no entry of its own
+    half = (ConvDesc * na)()
+    for i in range(na):
+        _fill_desc(half[i], xs[i], pcs[i], ys[i], False, None, None, False, False, affs[i] if affs is not None else None)
+    key = _problem_key(half, na)
+    tv = FORCE_VARIANT if FORCE_VARIANT is not None else _TUNED.get(key)
+    if tv is None:
+        tv = (6, 16, 1) if _default_is_wino6(half, na, pc_a) else None
+    if tv is None or tv[0] != 6 or tv[2] != 1:
+        return None
+    _set_variant(descs, n, tv)
+    nimg, dev = xs[0].t.shape[0], xs[0].t.device
+    recs_l = [lib.cmk_conv_gn_records(y.t.shape[1], y.t.shape[2], 6) for y in ys]
+    gws = torch.empty((nimg * sum(recs_l), groups, 2), dtype=torch.float64, device=dev)
+    for i in range(n):
+        descs[i].gn_ws, descs[i].gn_groups = gws.data_ptr(), groups
+    taps = 9
+    if PROFILE is None:
+        check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi (tower pair)")
+    else:
+        flops = sum(2.0 * y.t.shape[0] * y.t.shape[1] * y.t.shape[2] * pc_a.cin * pc_a.cout * taps for y in ys)
+        nbytes = sum(4.0 * y.t.shape[0] * y.t.shape[1] * y.t.shape[2] * (pc_a.cin + pc_a.cout) for y in ys) + 2 * 4.0 * pc_a.cin * pc_a.cout * taps
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.cmk_conv2d_nhwc_multi(descs, n, _stream()), "cmk_conv2d_nhwc_multi (tower pair)")
+        e1.record()
+        PROFILE.append((_kernel_name(taps, 1, tv, affs is not None), flops, nbytes, e0, e1, None,
+                        executed_flops(taps, 1, tv, [tuple(y.t.shape[:3]) for y in ys], pc_a.cin_pad, pc_a.cout)))
+    out = []
+    rec_off = 0
+    for t, (gamma, beta) in enumerate((gn_a, gn_b)):
+        sl = slice(t * na, (t + 1) * na)
+        res = [(torch.empty((nimg, pc_a.cout), dtype=torch.float32, device=dev), torch.empty((nimg, pc_a.cout), dtype=torch.float32, device=dev)) for _ in range(na)]
+        hs, wss, recs = (ctypes.c_int * na)(), (ctypes.c_int * na)(), (ctypes.c_int * na)()
+        ps, pb = (ctypes.c_void_p * na)(), (ctypes.c_void_p * na)()
+        for i, y in enumerate(ys[sl]):
+            hs[i], wss[i], recs[i] = y.t.shape[1], y.t.shape[2], recs_l[t * na + i]
+            ps[i], pb[i] = res[i][0].data_ptr(), res[i][1].data_ptr()
+        # the records of the second tower's problems follow those of the first (spatial tiles are numbered problem after problem)
+        check(lib.cmk_groupnorm_affine_tiles(gws.data_ptr() + rec_off * groups * 2 * 8, hs, wss, recs, na, gamma.data_ptr(), beta.data_ptr(), nimg, pc_a.cout,
+                                             groups, eps, ps, pb, _stream()), "cmk_groupnorm_affine_tiles")
+        rec_off += nimg * sum(recs_l[sl])
+        out.append((ys[sl], res))
+    return out[0], out[1]
 
 
 def conv_out_multi(xs: Sequence[View], pcs: Sequence[PackedConv], **kw) -> List[View]:  # kw: relu, relu_upto, in_affine

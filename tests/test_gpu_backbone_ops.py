@@ -587,6 +587,40 @@ def test_conv_with_fused_groupnorm_statistics(dev, cout, groups, form, monkeypat
         _close(sh, ref_sh, 1e-4)
 
 
+@pytest.mark.parametrize("sc", [16, 64])
+@pytest.mark.parametrize("with_affine", [False, True])
+def test_tower_pair_launch_equals_two_launches(dev, sc, with_affine, monkeypatch):
+    """ops.conv_gn_multi_pair: conv k of two towers with different weights as ONE launch of 2 x levels problems (per-problem packed weights
+    in the F(4x4) kernels) — outputs and GroupNorm affines bit-identical to two conv_gn_multi launches, with and without the fused input
+    affine of the previous GroupNorm."""
+    monkeypatch.setattr(ops, "FORCE_VARIANT", (6, sc, 1))
+    g = torch.Generator().manual_seed(77)
+    shapes = [(2, 20, 36), (2, 9, 17), (2, 5, 3), (2, 3, 2), (2, 1, 1)]
+    cin = cout = 64
+    groups = 32
+    wa = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    wb = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    pca = ops.PackedConv(wa, None, torch.randn((cout,), generator=g) * 0.1, dev)
+    pcb = ops.PackedConv(wb, None, torch.randn((cout,), generator=g) * 0.1, dev)
+    gn = [((torch.rand((cout,), generator=g) + 0.5).to(dev), (torch.randn((cout,), generator=g) * 0.1).to(dev)) for _ in range(2)]
+    xs = [ops.as_view(torch.randn((n, cin, h, w), generator=g).to(dev)) for n, h, w in shapes]
+    aff_a = aff_b = None
+    if with_affine:
+        aff_a = [((torch.rand((n, cin), generator=g) + 0.5).to(dev), (torch.randn((n, cin), generator=g) * 0.2).to(dev)) for n, _, _ in shapes]
+        aff_b = [((torch.rand((n, cin), generator=g) + 0.5).to(dev), (torch.randn((n, cin), generator=g) * 0.2).to(dev)) for n, _, _ in shapes]
+    pair = ops.conv_gn_multi_pair(xs, pca, gn[0], xs, pcb, gn[1], groups, 1e-5, in_affine_a=aff_a, in_affine_b=aff_b)
+    assert pair is not None
+    ya, affa = ops.conv_gn_multi(xs, [pca] * 5, gn[0][0], gn[0][1], groups, 1e-5, in_affine=aff_a)
+    yb, affb = ops.conv_gn_multi(xs, [pcb] * 5, gn[1][0], gn[1][1], groups, 1e-5, in_affine=aff_b)
+    torch.cuda.synchronize()
+    for (ys, affs), (ys_ref, affs_ref) in zip(pair, ((ya, affa), (yb, affb))):
+        for y, yr, (sc_, sh_), (scr, shr) in zip(ys, ys_ref, affs, affs_ref):
+            assert torch.equal(y.t, yr.t) and torch.equal(sc_, scr) and torch.equal(sh_, shr)
+    # the library refuses different weights per problem on the kernels that take one weight pointer per launch
+    monkeypatch.setattr(ops, "FORCE_VARIANT", (5, 16, 2))
+    assert ops.conv_gn_multi_pair(xs, pca, gn[0], xs, pcb, gn[1], groups, 1e-5) is None
+
+
 def test_groupnorm_affine_multi_level(dev):
     shapes = [(100, 160), (13, 20), (7, 10), (1, 2)]
     gamma = torch.rand(256, generator=torch.Generator().manual_seed(42)) + 0.5
