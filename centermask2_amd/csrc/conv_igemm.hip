@@ -969,13 +969,23 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
     if (d->tune_wm == 6) {          // Winograd F(4x4,3x3): same conditions, its own packed weights
         if (d->ksize != 3 || d->stride != 1 || d->res_mode != 0 || d->in_relu || !d->w_wino6 || (d->Cin & 7))
             return fail(CMK_EINVAL, "conv: Winograd F(4x4,3x3) variant not available for this conv%s", "");
-        if (d->splitk > 1) return fail(CMK_EINVAL, "conv: split-K is a direct-kernel feature%s", "");
         if (d->gn_ws) {
             int rc = setup_gn(a, d);
             if (rc) return rc;
         }
         a.w = d->w_wino6;
-        a.ws = d->splitk_ws;          // instrumented builds (W6_TRACE) only: a stamp buffer; unused otherwise
+        a.ws = d->splitk_ws;          // split-K slabs (instrumented W6_TRACE builds: a stamp buffer)
+        a.ksplit = d->splitk > 1 ? d->splitk : 1;
+        a.cout_pad = cmk_conv_cout_pad(d->Cout);
+        if (a.ksplit > 1) {           // F(4x4) with split-K (32-cout form, map tiles): partial sums + the reduce kernel of the direct path
+            if (d->tune_sc == 64 || d->tune_wn != 1 || n != 1) return fail(CMK_EINVAL, "conv: Winograd split-K needs tune_sc 16, tune_wn 1, one problem%s", "");
+            int rc = launch_wino6(a, 0, st);
+            if (rc) return rc;
+            const ConvProblem& p = a.p[0];
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((p.total_pix * (a.cout_pad >> 2) + 255) / 256, 256L * 32)), dim3(256), 0, st, a.ws, a.ksplit,
+                               p.total_pix, a.cout_pad, p.scale, p.shift, a.Cout, a.relu_upto, (const float*)nullptr, 0, 0, p.y, a.y_cs, a.y_co);
+            return check_launch("splitk_reduce");
+        }
         if (d->tune_wn != 1 && d->tune_wn != 2) return fail(CMK_EINVAL, "conv: tune_wm 6 takes tune_wn 1 (12x40 map tiles) or 2 (pairs of RoI maps up to 16x14)%s", "");
         if (d->tune_sc == 64) return launch_wino6s(a, d->tune_wn == 2 ? 1 : 0, st);      // 64 couts per workgroup, shared frequency image
         return launch_wino6(a, d->tune_wn == 2 ? 1 : 0, st);

@@ -97,7 +97,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
         n = tile * 2; oh0 = 0; ow0 = 0;
     }
     const int co0 = by * 32;
-    const int nchunks = a.Cin >> 3;
+    // split-K (a.ksplit > 1, blockIdx.y): this workgroup owns the 8-channel chunks [c_lo, nchunks) of the conv's Cin / 8 and leaves raw partial
+    // sums in a.ws (see the epilogue); for launches of about one round of workgroups whose life is one long chunk loop (the first conv of a
+    // stage-4 / stage-5 OSA block: 512..1024 input channels on 50x80 / 25x40 maps) two or four workgroups share that loop
+    const int ks = blockIdx.y;
+    const int c_lo = (int)((long)ks * (a.Cin >> 3) / a.ksplit);
+    const int nchunks = (int)((long)(ks + 1) * (a.Cin >> 3) / a.ksplit);       // END of this workgroup's chunk range (even bounds: host)
 
     // ---- pass 1 item of this thread ----------------------------------------------------------------------------------------------
     int p_img, p_q, p_t, p_col;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) ub[buf][k] = *reinterpret_cast<const f32x4*>(src + (u_lane_off + k * 256));
     };
-    const int total_steps = nchunks * 3;
+    const int total_steps = nchunks * 3;                        // END of the step range
 
 #ifdef W6_TRACE
     // instrumented build (tools/ab/trace_wino6.py): lane 0 of every wave of every 16th workgroup stamps the shader clock into a.ws
@@ -223,14 +228,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     W6_STAMP();                                       // 0: start
     // ---- prologue ----------------------------------------------------------------------------------------------------------------
     // the halos of chunks 0 and 1 and the first weights are requested together: one memory round trip before the first MFMA
-    load_D(0);
+    load_D(c_lo);
     f32x4 d_first[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) d_first[i] = d[i];
     f32x4 sc_first = in_sc, sh_first = in_sh;
-    load_D(min(1, nchunks - 1));
-    load_U(0, 0);
-    load_U(min(1, total_steps - 1), 1);
+    load_D(min(c_lo + 1, nchunks - 1));
+    load_U(c_lo * 3, 0);
+    load_U(min(c_lo * 3 + 1, total_steps - 1), 1);
     {
         f32x4 d_keep[6], sc_keep = in_sc, sh_keep = in_sh;
 #pragma unroll
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
         half_stepB(xb, 1);
         W6_STAMP_AT(56);                              // step 2 issued
     };
-    for (int c = 0; c < nchunks; c += 2) {        // nchunks is even: Cin is a multiple of 16 (validate)
+    for (int c = c_lo; c < nchunks; c += 2) {     // an even number of chunks: Cin is a multiple of 16 (validate), split-K bounds are even (host)
         period(c, std::integral_constant<int, 0>{});
         period(c + 1, std::integral_constant<int, 1>{});
     }
@@ -386,25 +391,31 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
     // (measured: 340 ns per store, 26 us of a 76 us workgroup).  Wait once here and hand the values over through an asm the pass
     // cannot see through: from now on they are plain register values.
     asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(sc), "+v"(sh) : : "memory");
+    // split-K: raw partial sums (no scale / shift / ReLU) go to this split's slab of a.ws, laid out [pixel][cout_pad]; the reduce kernel of
+    // conv_igemm.hip sums the slabs in a fixed order and applies the epilogue
+    const bool raw = a.ksplit > 1;
+    float* const ybuf = raw ? a.ws + (long)ks * P.total_pix * a.cout_pad : P.y;
+    const int ycs = raw ? a.cout_pad : a.y_cs, yco = raw ? 0 : a.y_co;
+    if (raw) { sc = 1.f; sh = 0.f; }
     // Everything below works on PAIRS of accumulator registers (r, r+1 = two tiles of the lane) with packed-fp32 instructions, and the
     // stores of interior tiles take a wave-uniform (row, column) base from the scalar unit plus one lane offset per tile: a VALU instruction
     // issued here waits for a gap in the MFMA stream of the other workgroup on the SIMD and takes the slot from it (trace: this epilogue
     // ran 12.4 us next to a partner, 5.6 us alone), so the epilogue is priced in VALU instructions — 3x fewer than the scalar form.
     f32x2* ex2 = reinterpret_cast<f32x2*>(smem);        // exchange: [src wave][dst wave][value 0..7][lane] pairs = 64 KiB
-    const float lo = co < a.relu_upto ? 0.f : __builtin_nanf("");      // max(v, NaN) = v: lanes without the ReLU
+    const float lo = (co < a.relu_upto && !raw) ? 0.f : __builtin_nanf("");      // max(v, NaN) = v: lanes without the ReLU
     const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
     auto fma2 = [](f32x2 x, float k, f32x2 y) { return __builtin_elementwise_fma(x, f32x2{k, k}, y); };
     const bool want_stats = a.gn_ws != nullptr;
     f32x2 gs2 = {0.f, 0.f}, gss2 = {0.f, 0.f};
     float gs = 0.f, gss = 0.f;
-    float* yimg = P.y + (long)n * H * W * a.y_cs + a.y_co + co;
+    float* yimg = ybuf + (long)n * H * W * ycs + yco + co;
     // scalar side of the store addresses: image base (the pair's first image for GEO 1) and the byte strides of one pixel / one row
     unsigned long long ybase_s;
     {
-        const unsigned long long yb = (unsigned long long)(P.y + (long)n * H * W * a.y_cs);
+        const unsigned long long yb = (unsigned long long)(ybuf + (long)n * H * W * ycs);
         ybase_s = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(yb >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)yb);
     }
-    const unsigned long long px_b = (unsigned long long)a.y_cs * 4u, rowskip_b = (unsigned long long)(W - 3) * a.y_cs * 4u;
+    const unsigned long long px_b = (unsigned long long)ycs * 4u, rowskip_b = (unsigned long long)(W - 3) * ycs * 4u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         f32x2 own[8];
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
             const bool tile_ok = cvalid && m < G::TILES && n + mimg < P.N;
             full[rr] = tile_ok && oh + 4 <= H && ow + 4 <= W;
             if (full[rr]) {                             // interior tile: 16 stores, no per-store predicate, no vector address arithmetic
-                const unsigned voff = (unsigned)((((mimg * H + oh) * W + ow) * a.y_cs + a.y_co + co) * 4);
+                const unsigned voff = (unsigned)((((mimg * H + oh) * W + ow) * ycs + yco + co) * 4);
                 unsigned long long sp = ybase_s;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -502,14 +513,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvArgs a) {
                         sp += j == 3 ? rowskip_b : px_b;
                     }
             } else if (tile_ok) {
-                float* yp0 = yimg + (((long)mimg * H + oh) * W + ow) * a.y_cs;
+                float* yp0 = yimg + (((long)mimg * H + oh) * W + ow) * ycs;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (oh + i < H && ow + j < W) {
                             const float val = rr ? yv[i][j].y : yv[i][j].x;
-                            yp0[((long)i * W + j) * a.y_cs] = val;
+                            yp0[((long)i * W + j) * ycs] = val;
                             gs += val;
                             gss = fmaf(val, val, gss);
                         }
@@ -573,7 +584,8 @@ static int launch_wino6_geo(ConvArgs& a, hipStream_t st) {
     }
     a.grid_y = cdiv(a.Cout, 32);
     a.total_tiles = blocks;
-    const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y);
+    if (a.ksplit < 1) a.ksplit = 1;
+    const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y, a.ksplit);
     if (a.p[0].in_scale)
         hipLaunchKernelGGL((conv_wino6_kernel<true, GEO>), grid, dim3(256), w6_lds_alloc<GEO>(), st, a);
     else
@@ -584,8 +596,10 @@ static int launch_wino6_geo(ConvArgs& a, hipStream_t st) {
 // geo 0: 12x40-pixel tiles of one image; geo 1: pairs of whole maps of at most 16 rows x 14 columns (one problem, no fused GN statistics)
 int launch_wino6(ConvArgs& a, int geo, hipStream_t st) {
     for (int i = 0; i < a.nprob; ++i)       // the epilogue's stores take a 32-bit byte offset inside the output image (GEO 1: inside a pair of images)
-        if ((long)(geo == 0 ? 1 : 2) * a.p[i].H * a.p[i].W * a.y_cs * 4 >= (1L << 32))
+        if ((long)(geo == 0 ? 1 : 2) * a.p[i].H * a.p[i].W * std::max(a.y_cs, a.cout_pad) * 4 >= (1L << 32))
             return fail(CMK_EINVAL, "conv_wino6: an output image of 4 GiB or more%s", "");
+    if (a.ksplit > 1 && (a.nprob != 1 || a.gn_ws || !a.ws || ((a.Cin >> 3) % (2 * a.ksplit)) || a.cout_pad < cdiv(a.Cout, 32) * 32))
+        return fail(CMK_EINVAL, "conv_wino6: split-K takes one problem, no GroupNorm statistics, a workspace and Cin / 8 chunks %% (2 * splitk) == 0%s", "");
     if (geo == 0) return launch_wino6_geo<0>(a, st);
     if (a.nprob != 1 || a.p[0].H > 16 || a.p[0].W > 14 || a.gn_ws)
         return fail(CMK_EINVAL, "conv_wino6: the RoI-pair geometry takes one problem of maps up to 16x14 and produces no GroupNorm statistics%s", "");

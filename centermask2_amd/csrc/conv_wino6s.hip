@@ -750,6 +750,7 @@ static int launch_wino6s_geo(ConvArgs& a, hipStream_t st) {
     }
     a.grid_y = cdiv(cdiv(a.Cout, 32), 2);
     a.total_tiles = blocks;
+    if (a.ksplit > 1) return fail(CMK_EINVAL, "conv_wino6s: split-K is a feature of the 32-cout form (tune_sc 16)%s", "");
     const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y);
     if (a.p[0].in_scale)
         hipLaunchKernelGGL((conv_wino6s_kernel<true, GEO>), grid, dim3(512), W6S<GEO>::LDS_BYTES, st, a);

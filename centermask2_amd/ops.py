@@ -301,6 +301,8 @@ def _tune(descs, n, key) -> None:
         cands += [(5, 16, 2, 1)]                  # fused Winograd F(2x2,3x3)
         cands += [(6, 16, 1, 1), (6, 16, 2, 1)]   # fused Winograd F(4x4,3x3): map tiles / pairs of RoI maps (the library rejects what does not apply)
         cands += [(6, 64, 1, 1), (6, 64, 2, 1)]   # ... its shared-V form: 64 couts per workgroup from one frequency image (conv_wino6s.hip)
+        if small and d0.ksize == 3:
+            cands += [(6, 16, 1, sk) for sk in (2, 4)]      # ... with the chunk loop split over 2 / 4 workgroups (launches of about one round)
     for tv in cands:
         ws = _set_variant(descs, n, tv)
         if run() != 0:

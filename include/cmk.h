@@ -92,7 +92,11 @@ typedef struct {
      * per 4x4 outputs, 1.78x fewer than F(2x2,3x3); fp32 throughout, error ~1.6x the 2x2 form's (tools/wino_numerics.py).  Needs
      * U = G g G^T (6x6 per filter, points 0, +-1, +-2, inf), cmk_wino6_packed_floats floats packed
      * [Cin/8][ceil(Cout/32)][wave 4][slot 9][lane 64][4 floats]: slot k < 6 is frequency (row = wave, column = k), slot k >= 6 is
-     * (row = 4 + wave/2, column = 3*(wave%2) + k - 6); output channel = tile*32 + (lane & 31), input channel = chunk*8 + 4*(lane >> 5) + j. */
+     * (row = 4 + wave/2, column = 3*(wave%2) + k - 6); output channel = tile*32 + (lane & 31), input channel = chunk*8 + 4*(lane >> 5) + j.
+     * tune_sc == 64 with tune_wm == 6 selects the "shared V" form of the same arithmetic (conv_wino6s.hip; tune_sc 16 or 0 = conv_wino6.hip): one
+     * 8-wave workgroup per CU computes 64 output channels of a spatial tile from ONE frequency image of the input kept in LDS, so the halo is
+     * fetched and transformed once per 64 channels instead of once per 32; same packed weights, same K order: bit-identical results.  It is
+     * the faster form for launches of about one round of workgroups (the 50x80 maps of stage 4, vovnet.py:90-98); the start-up tuner decides. */
     const float* w_wino6;
     /* optional fused average-pool partial sums of the (scaled, shifted, ReLU'd) OUTPUT, for the eSE gate of the OSA aggregation conv
      * (vovnet.py:255-256 avg_pool over the conv the block just produced): only the pointwise GEMM kernel produces them — ask
@@ -106,7 +110,11 @@ int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
 int cmk_conv_pool_rows(const cmk_conv_desc* d);
 /* Same conv applied to up to 5 inputs of different H x W in ONE launch (the FCOS towers/predictors share their weights
  * across the FPN levels, fcos.py:227-238).  All descriptors must share w, Cin, Cout, ksize, stride, views and flags and
- * carry no residual; x, y, N, H, W, scale, shift may differ. */
+ * carry no residual; x, y, N, H, W, scale, shift, in_scale/in_shift may differ.
+ * With tune_wm == 6, tune_wn == 1 (the F(4x4) map kernels, which take the packed weights per problem) the problems may also differ in their
+ * weights (w, w_wino6) and there may be up to 10 of them: conv k of the FCOS head's cls tower and of its bbox tower — same level shapes,
+ * different weights, fcos.py:227-231 — run as one launch of 2 x 5 problems.  Fused GroupNorm records (gn_ws) are numbered over the spatial
+ * tiles of all problems in order, so the records of problems 5..9 follow those of problems 0..4. */
 int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* stream);
 /* number of floats of the packed layout for (Cout, Cin, k): taps * ceil(Cin/16) * cout_pad * 16 */
 int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize);

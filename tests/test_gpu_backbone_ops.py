@@ -408,6 +408,29 @@ def test_conv_winograd6_variant(dev, case):
     assert torch.equal(y.t, y3.t), "conv_wino6s differs from conv_wino6"
 
 
+@pytest.mark.parametrize("case", [(2, 25, 40, 768, 224, 4), (1, 50, 80, 512, 192, 2), (2, 13, 41, 64, 33, 2), (1, 12, 40, 128, 256, 8)])
+def test_conv_winograd6_split_k(dev, case):
+    """tune_wm 6 with split-K: 2 / 4 / 8 workgroups share the chunk loop of one (spatial tile, cout tile), raw partial sums go to the
+    workspace, conv_igemm's reduce kernel sums them in a fixed order and applies the epilogue — for launches of about one round of
+    workgroups with hundreds of input channels (the first conv of a stage-4 / stage-5 OSA block).  fp32 rounding differences only;
+    chunk counts that do not split evenly and the shared-V form are refused."""
+    n, h, w, cin, cout, sk = case
+    x = _rand((n, cin, h, w), 181)
+    wt = _rand((cout, cin, 3, 3), 182, (2.0 / (cin * 9)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(183)) + 0.5
+    shift = _rand((cout,), 184, 0.1)
+    ref = F.relu(F.conv2d(x, wt, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    rc, y = _run_variant(dev, x, wt, scale, shift, (6, 16, 1, sk))
+    assert rc == 0
+    _close(y.nchw(), ref)
+    rc2, y2 = _run_variant(dev, x, wt, scale, shift, (6, 16, 1, sk))      # deterministic: a second launch gives the same bits
+    assert rc2 == 0 and torch.equal(y.t, y2.t)
+    rc, _ = _run_variant(dev, x, wt, scale, shift, (6, 64, 1, sk))        # the shared-V form has no split-K
+    assert rc != 0
+    rc, _ = _run_variant(dev, _rand((1, 48, 12, 40), 185), _rand((32, 48, 3, 3), 186, 0.05), None, None, (6, 16, 1, 4))      # 6 chunks % 8 != 0
+    assert rc != 0
+
+
 @pytest.mark.parametrize("case", [(6, 14, 14, 256, 80), (5, 14, 14, 272, 256), (3, 16, 14, 32, 64), (2, 7, 7, 64, 32), (1, 14, 14, 64, 33)])
 def test_conv_winograd6_roi_pair_geometry(dev, case):
     """tune_wm 6 / tune_wn 2: two whole RoI maps (at most 16 rows x 14 columns) per workgroup — even and odd batch, the 272-channel
