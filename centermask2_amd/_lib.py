@@ -57,6 +57,8 @@ SIGNATURES = {
     "cmk_ese_gate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_ese_scale": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_groupnorm_relu_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "cmk_groupnorm_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "cmk_upsample2x_add_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_groupnorm_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "cmk_groupnorm_affine_multi": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                            POINTER(c_void_p), POINTER(c_void_p), c_void_p]),

@@ -363,7 +363,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const double* __restrict__ ws, int HW, int C, int groups, int chunks, float eps,
-                                                      int blocks_per_image) {
+                                                      int blocks_per_image, float lo) {
+    // lo: 0 = GroupNorm + ReLU, -inf = GroupNorm alone (max(v, -inf) = v)
     __shared__ float s_mean[64], s_rstd[64];
     const int n = blockIdx.y;
     if (threadIdx.x < groups) {
@@ -391,10 +392,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(float* __restrict__ x, co
         f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
         f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
         f32x4 o;
-        o.x = fmaxf((v.x - mean) * rstd * ga.x + be.x, 0.f);
-        o.y = fmaxf((v.y - mean) * rstd * ga.y + be.y, 0.f);
-        o.z = fmaxf((v.z - mean) * rstd * ga.z + be.z, 0.f);
-        o.w = fmaxf((v.w - mean) * rstd * ga.w + be.w, 0.f);
+        o.x = fmaxf((v.x - mean) * rstd * ga.x + be.x, lo);
+        o.y = fmaxf((v.y - mean) * rstd * ga.y + be.y, lo);
+        o.z = fmaxf((v.z - mean) * rstd * ga.z + be.z, lo);
+        o.w = fmaxf((v.w - mean) * rstd * ga.w + be.w, lo);
         *reinterpret_cast<f32x4*>(xn + i * 4) = o;
     }
 }
@@ -601,8 +602,45 @@ extern "C" int cmk_ese_scale(const float* x, int x_cs, int x_co, const float* ga
     return check_launch("ese_scale");
 }
 
+// nearest-neighbour 2x upsampling of `coarse` added to `y` in place (d2 FPN's top-down path, ctor at vovnet.py:547-554, when a norm sits between the
+// lateral conv and the sum, so that the sum cannot ride in the conv's epilogue)
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(float* __restrict__ y, const float* __restrict__ c, int N, int H, int W, int Hc, int Wc, int C4) {
+    long total = (long)N * H * W * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = (int)(i % C4);
+        long p = i / C4;
+        int w = (int)(p % W);
+        int h = (int)((p / W) % H);
+        int n = (int)(p / ((long)W * H));
+        const f32x4 a = *reinterpret_cast<const f32x4*>(y + i * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(c + ((((long)n * Hc + (h >> 1)) * Wc + (w >> 1)) * C4 + c4) * 4);
+        *reinterpret_cast<f32x4*>(y + i * 4) = f32x4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+    }
+}
+
+extern "C" int cmk_upsample2x_add_nhwc(float* y, const float* coarse, int N, int H, int W, int Hc, int Wc, int C, void* stream) {
+    if (!y || !coarse) return fail(CMK_EINVAL, "upsample2x_add: null pointer%s", "");
+    if ((C & 3) || N < 1 || H < 1 || W < 1 || Hc * 2 < H || Wc * 2 < W) return fail(CMK_EINVAL, "upsample2x_add: C %% 4 == 0 and a coarse map of at least half the size%s", "");
+    long total = (long)N * H * W * (C >> 2);
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, y, coarse, N, H, W, Hc, Wc, C >> 2);
+    return check_launch("upsample2x_add");
+}
+
+static int groupnorm_inplace(float* x, const float* gamma, const float* beta, double* ws, int ws_chunks, int N, int HW, int C, int groups, float eps,
+                             float lo, void* stream);
+
 extern "C" int cmk_groupnorm_relu_nhwc(float* x, const float* gamma, const float* beta, double* ws, int ws_chunks, int N, int HW, int C,
                                        int groups, float eps, void* stream) {
+    return groupnorm_inplace(x, gamma, beta, ws, ws_chunks, N, HW, C, groups, eps, 0.f, stream);
+}
+
+extern "C" int cmk_groupnorm_nhwc(float* x, const float* gamma, const float* beta, double* ws, int ws_chunks, int N, int HW, int C,
+                                  int groups, float eps, void* stream) {
+    return groupnorm_inplace(x, gamma, beta, ws, ws_chunks, N, HW, C, groups, eps, -INFINITY, stream);
+}
+
+static int groupnorm_inplace(float* x, const float* gamma, const float* beta, double* ws, int ws_chunks, int N, int HW, int C, int groups, float eps,
+                             float lo, void* stream) {
     if (!x || !gamma || !beta || !ws) return fail(CMK_EINVAL, "groupnorm: null pointer%s", "");
     if ((C & 3) || C > 1024 || groups < 1 || groups > 64 || C % groups || ((C / groups) & 3) || 256 % (C >> 2) || ws_chunks < 1)
         return fail(CMK_EINVAL, "groupnorm: unsupported C/groups%s", "");
@@ -613,7 +651,7 @@ extern "C" int cmk_groupnorm_relu_nhwc(float* x, const float* gamma, const float
     int bpi = stream_grid(total);
     if (bpi > 1024) bpi = 1024;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, ws, HW, C, groups, ws_chunks, eps,
-                       bpi);
+                       bpi, lo);
     return check_launch("gn_apply");
 }
 

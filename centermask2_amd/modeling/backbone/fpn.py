@@ -12,7 +12,7 @@ from torch import nn
 
 from ... import ops
 from ...ops import View
-from ..base import Backbone, HipModule
+from ..base import Backbone, HipModule, NormConv2d, fold_norm, get_norm
 
 __all__ = ["FPN", "LastLevelP6P7", "LastLevelP6", "LastLevelMaxPool"]
 
@@ -47,8 +47,6 @@ class LastLevelMaxPool(nn.Module):
 class FPN(Backbone):
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
         super().__init__()
-        if norm != "":
-            raise NotImplementedError("FPN norm '{}' (the reference config uses '')".format(norm))
         if fuse_type != "sum":
             raise NotImplementedError("FPN fuse_type '{}' (the reference config uses 'sum')".format(fuse_type))
         input_shapes = bottom_up.output_shape()
@@ -57,8 +55,11 @@ class FPN(Backbone):
             assert b == 2 * a, "FPN input strides must double: {}".format(strides)
         self._stages = [int(math.log2(s)) for s in strides]
         for f, st in zip(in_features, self._stages):
-            self.add_module("fpn_lateral{}".format(st), nn.Conv2d(input_shapes[f].channels, out_channels, kernel_size=1))
-            self.add_module("fpn_output{}".format(st), nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1))
+            # d2 FPN: bias only without a norm; MODEL.FPN.NORM (vovnet.py:550) "" in the reference recipe, "GN" / "FrozenBN" / "BN" as get_norm
+            self.add_module("fpn_lateral{}".format(st), NormConv2d(input_shapes[f].channels, out_channels, kernel_size=1, bias=norm == "",
+                                                                    norm=get_norm(norm, out_channels)))
+            self.add_module("fpn_output{}".format(st), NormConv2d(out_channels, out_channels, kernel_size=3, padding=1, bias=norm == "",
+                                                                   norm=get_norm(norm, out_channels)))
         self.top_block = top_block
         self.in_features = tuple(in_features)
         self.bottom_up = bottom_up
@@ -79,8 +80,10 @@ class FPN(Backbone):
         P = {}
         for st in self._stages:
             lat, out = getattr(self, "fpn_lateral{}".format(st)), getattr(self, "fpn_output{}".format(st))
-            P["lat{}".format(st)] = ops.PackedConv(lat.weight, None, lat.bias, dev)
-            P["out{}".format(st)] = ops.PackedConv(out.weight, None, out.bias, dev)
+            for name, conv in (("lat", lat), ("out", out)):
+                scale, shift, gn = fold_norm(conv)
+                P["{}{}".format(name, st)] = ops.PackedConv(conv.weight, scale, shift, dev)
+                P["{}{}_gn".format(name, st)] = None if gn is None else (gn[0].contiguous().to(dev), gn[1].contiguous().to(dev), gn[2], gn[3])
         if self.top_block is not None and not isinstance(self.top_block, LastLevelMaxPool):
             P["p6"] = ops.PackedConv(self.top_block.p6.weight, None, self.top_block.p6.bias, dev, stride=2)
             if self.top_block.num_levels == 2:
@@ -97,8 +100,18 @@ class FPN(Backbone):
             if prev is not None and (prev.t.shape[1] * 2 != c.t.shape[1] or prev.t.shape[2] * 2 != c.t.shape[2]):
                 raise ValueError("FPN: feature {} is {}x{}, not twice the level above ({}x{}); pad the input to a multiple of {}"
                                  .format(f, c.t.shape[1], c.t.shape[2], prev.t.shape[1], prev.t.shape[2], self._size_divisibility))
-            prev = ops.conv_out(c, P["lat{}".format(st)], res=prev, res_upsample=prev is not None)  # lateral + up2(top-down)
+            lat_gn, out_gn = P["lat{}_gn".format(st)], P["out{}_gn".format(st)]
+            if lat_gn is None:
+                prev = ops.conv_out(c, P["lat{}".format(st)], res=prev, res_upsample=prev is not None)  # lateral + up2(top-down) in the epilogue
+            else:                                           # a GroupNorm sits between the lateral conv and the sum
+                lat = ops.conv_out(c, P["lat{}".format(st)])
+                ops.groupnorm_relu_(lat.t, lat_gn[0], lat_gn[1], lat_gn[3], lat_gn[2], relu=False)
+                if prev is not None:
+                    ops.upsample2x_add_(lat, prev)
+                prev = lat
             results["p{}".format(st)] = ops.conv_out(prev, P["out{}".format(st)])
+            if out_gn is not None:
+                ops.groupnorm_relu_(results["p{}".format(st)].t, out_gn[0], out_gn[1], out_gn[3], out_gn[2], relu=False)
         if self.top_block is not None:
             src_name = self.top_block.in_feature
             src = bu[src_name] if src_name in bu else results[src_name]

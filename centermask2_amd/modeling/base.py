@@ -71,3 +71,43 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("bias", torch.zeros(num_features))
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+
+def get_norm(norm: str, out_channels: int):
+    """detectron2's get_norm for the names an inference path can meet: "" -> None, "FrozenBN", "BN" / "SyncBN" (their eval form: running
+    statistics), "GN" (32 groups).  The returned module only HOLDS the parameters (state-dict names of d2's Conv2d wrapper: `<conv>.norm.*`);
+    the arithmetic is folded into the conv's epilogue (batch norms) or runs as the GroupNorm kernel."""
+    if not norm:
+        return None
+    if norm == "FrozenBN":
+        return FrozenBatchNorm2d(out_channels)
+    if norm in ("BN", "SyncBN"):
+        return nn.BatchNorm2d(out_channels)
+    if norm == "GN":
+        return nn.GroupNorm(32, out_channels)
+    raise NotImplementedError("norm '{}'".format(norm))
+
+
+class NormConv2d(nn.Conv2d):
+    """nn.Conv2d with detectron2's optional `norm` child (d2 `Conv2d(..., norm=get_norm(name, C))`: parameters `weight`[, `bias`], `norm.*`)."""
+
+    def __init__(self, *args, norm=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+
+
+def fold_norm(conv: nn.Conv2d):
+    """(scale, shift, gn) of a conv's epilogue: batch norms fold with the bias into per-channel scale/shift (eval statistics);
+    a GroupNorm stays a pass of its own: gn = (gamma, beta, eps, groups), applied to conv(x) + bias."""
+    norm = getattr(conv, "norm", None)
+    bias = conv.bias.detach().float().cpu() if conv.bias is not None else None
+    if norm is None:
+        return None, bias, None
+    if isinstance(norm, nn.GroupNorm):
+        return None, bias, (norm.weight.detach().float(), norm.bias.detach().float(), norm.eps, norm.num_groups)
+    w, b = norm.weight.detach().double().cpu(), norm.bias.detach().double().cpu()
+    scale = w / torch.sqrt(norm.running_var.detach().double().cpu() + norm.eps)
+    shift = b - norm.running_mean.detach().double().cpu() * scale
+    if bias is not None:
+        shift = shift + bias.double() * scale
+    return scale.float(), shift.float(), None

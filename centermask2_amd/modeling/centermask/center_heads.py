@@ -21,7 +21,7 @@ from ... import ops
 from ...ops import View
 from ...registry import ROI_HEADS_REGISTRY, ROI_MASK_HEAD_REGISTRY, ROI_MASKIOU_HEAD_REGISTRY
 from ...structures import Boxes, Instances, ShapeSpec
-from ..base import HipModule
+from ..base import HipModule, NormConv2d, fold_norm, get_norm
 
 __all__ = ["CenterROIHeads", "ROIPooler", "SpatialAttentionMaskHead", "MaskIoUHead", "build_mask_head", "build_maskiou_head"]
 
@@ -67,16 +67,17 @@ class SpatialAttentionMaskHead(HipModule):
         super().__init__()
         num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
         conv_dims = cfg.MODEL.ROI_MASK_HEAD.CONV_DIM
-        if cfg.MODEL.ROI_MASK_HEAD.NORM:
-            raise NotImplementedError("ROI_MASK_HEAD.NORM '{}' ('' in the reference)".format(cfg.MODEL.ROI_MASK_HEAD.NORM))
+        self.norm = cfg.MODEL.ROI_MASK_HEAD.NORM           # sam.py:53: "" in the reference recipe; "GN" / "FrozenBN" / "BN" as d2's get_norm
         num_conv = cfg.MODEL.ROI_MASK_HEAD.NUM_CONV
         self.cls_agnostic_mask = cfg.MODEL.ROI_MASK_HEAD.CLS_AGNOSTIC_MASK
         self.num_conv = num_conv
         self.conv_dims = conv_dims
         for k in range(num_conv):
-            conv = nn.Conv2d(input_shape.channels if k == 0 else conv_dims, conv_dims, kernel_size=3, stride=1, padding=1)
+            conv = NormConv2d(input_shape.channels if k == 0 else conv_dims, conv_dims, kernel_size=3, stride=1, padding=1, bias=not self.norm,
+                              norm=get_norm(self.norm, conv_dims))                     # sam.py:58-70
             nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
-            nn.init.constant_(conv.bias, 0)
+            if conv.bias is not None:
+                nn.init.constant_(conv.bias, 0)
             self.add_module("mask_fcn{}".format(k + 1), conv)
         self.spatialAtt = SpatialAttention()
         self.deconv = nn.ConvTranspose2d(conv_dims if num_conv > 0 else input_shape.channels, conv_dims, kernel_size=2, stride=2, padding=0)
@@ -88,7 +89,8 @@ class SpatialAttentionMaskHead(HipModule):
         P = {"convs": []}
         for k in range(self.num_conv):
             c = getattr(self, "mask_fcn{}".format(k + 1))
-            P["convs"].append(ops.PackedConv(c.weight, None, c.bias, dev))
+            scale, shift, gn = fold_norm(c)
+            P["convs"].append((ops.PackedConv(c.weight, scale, shift, dev), None if gn is None else (gn[0].contiguous().to(dev), gn[1].contiguous().to(dev), gn[2], gn[3])))
         P["sam_w"] = self.spatialAtt.conv.weight.detach().float().reshape(-1).contiguous().to(dev)      # [ci][kh][kw]
         # ConvTranspose2d k2 s2: out[2h+dh, 2w+dw, co] = sum_ci x[h,w,ci] W[ci,co,dh,dw] + b[co]  ==  a 1x1 conv with
         # 4*C outputs ordered (dh,dw,co)
@@ -105,8 +107,10 @@ class SpatialAttentionMaskHead(HipModule):
     def features(self, x: View, counts: torch.Tensor, topk: int) -> torch.Tensor:
         """conv x4 -> spatial attention -> relu(deconv): returns (R,S,S,4*C) with the 2x2 sub-pixels (dh,dw)-major."""
         P = self.packed()
-        for pc in P["convs"]:
-            x = ops.conv_out(x, pc, relu=True)
+        for pc, gn in P["convs"]:
+            x = ops.conv_out(x, pc, relu=gn is None)
+            if gn is not None:                                   # conv -> GroupNorm -> ReLU (sam.py:58-70 with NORM "GN")
+                ops.groupnorm_relu_(x.t, gn[0], gn[1], gn[3], gn[2])
         ops.spatial_attention_(x.t, P["sam_w"], counts, topk)
         return ops.conv_out(x, P["deconv"], relu=True).t
 

@@ -694,16 +694,25 @@ def groupnorm_affine_multi(xs: Sequence[torch.Tensor], gamma: torch.Tensor, beta
     return out
 
 
-def groupnorm_relu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-5) -> None:
-    """In place on a dense NHWC tensor (fcos.py:182-186)."""
+def groupnorm_relu_(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-5, relu: bool = True) -> None:
+    """GroupNorm (+ ReLU) in place on a dense NHWC tensor (fcos.py:182-186; relu=False: d2's get_norm("GN") behind a conv without activation)."""
     lib = _lib.load()
     _need_gpu(x, "groupnorm_relu_")
     n, h, w, c = x.shape
     hw = h * w
     chunks = max(1, min(128, hw // 128))
     ws = torch.empty((n, groups, chunks, 2), dtype=torch.float64, device=x.device)
-    check(lib.cmk_groupnorm_relu_nhwc(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), chunks, n, hw, c, groups,
-                                      eps, _stream()), "cmk_groupnorm_relu_nhwc")
+    fn = lib.cmk_groupnorm_relu_nhwc if relu else lib.cmk_groupnorm_nhwc
+    check(fn(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), chunks, n, hw, c, groups, eps, _stream()), "cmk_groupnorm[_relu]_nhwc")
+
+
+def upsample2x_add_(y: View, coarse: View) -> None:
+    """y += nearest-2x-upsampling(coarse), dense NHWC tensors (d2 FPN top-down sum behind a norm)."""
+    lib = _lib.load()
+    _need_gpu(y.t, "upsample2x_add_")
+    assert y.co == 0 and coarse.co == 0 and y.cs == y.c and coarse.cs == coarse.c and y.c == coarse.c, "upsample2x_add_ needs dense NHWC tensors"
+    n, h, w = y.nhw
+    check(lib.cmk_upsample2x_add_nhwc(y.t.data_ptr(), coarse.t.data_ptr(), n, h, w, coarse.t.shape[1], coarse.t.shape[2], y.c, _stream()), "cmk_upsample2x_add_nhwc")
 
 
 # ---------------------------------------------------------------------------------------------------------------

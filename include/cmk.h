@@ -160,6 +160,13 @@ int cmk_ese_gate_pooled(const float* pool_ws, int rows, const float* fc_w, const
 int cmk_groupnorm_relu_nhwc(float* x, const float* gamma, const float* beta, double* ws, int ws_chunks,
                             int N, int HW, int C, int groups, float eps, void* stream);
 
+/* The same without the ReLU (d2 get_norm("GN") behind a conv with no activation: MODEL.FPN.NORM "GN", vovnet.py:550) */
+int cmk_groupnorm_nhwc(float* x, const float* gamma, const float* beta, double* ws, int ws_chunks,
+                       int N, int HW, int C, int groups, float eps, void* stream);
+/* y (N,H,W,C dense) += nearest-neighbour 2x upsampling of coarse (N,Hc,Wc,C dense): d2 FPN's top-down sum when a norm sits between the
+ * lateral conv and the sum (otherwise the sum rides in the lateral conv's epilogue, cmk_conv_desc.res_mode 2) */
+int cmk_upsample2x_add_nhwc(float* y, const float* coarse, int N, int H, int W, int Hc, int Wc, int C, void* stream);
+
 /* Statistics only: out_scale/out_shift (N*C each) such that GroupNorm(x)[n,:,c] = x*out_scale[n,c] + out_shift[n,c];
  * the consumer conv applies them (cmk_conv_desc.in_scale/in_shift).  ws as above. */
 int cmk_groupnorm_affine(const float* x, const float* gamma, const float* beta, double* ws, int ws_chunks,

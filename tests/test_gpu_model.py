@@ -358,3 +358,48 @@ def test_thresh_with_ctr_model_matches_oracle(dev):
     assert k == want["scores"].shape[0] and k > 64
     assert torch.equal(det["cls"][0, :k].cpu(), want["classes"]) and torch.equal(det["loc"][0, :k].cpu(), want["locations"])
     close_abs(det["score"][0, :k], want["scores"], 1e-4, "thresh_with_ctr scores")
+
+
+@pytest.mark.parametrize("norm", ["GN", "FrozenBN"])
+def test_mask_head_norm_variants_match_reference(dev, norm):
+    """MODEL.ROI_MASK_HEAD.NORM (sam.py:53,66): the reference's own SpatialAttentionMaskHead with "GN" / "FrozenBN" convs (bias-free conv ->
+    norm -> ReLU), its state dict loaded by name into ours (tests/golden/make_golden_norms.py); all-class mask logits within 1e-3 absolute."""
+    from centermask2_amd.config import get_cfg, config_path
+    from centermask2_amd.modeling.centermask.center_heads import SpatialAttentionMaskHead
+    from centermask2_amd.structures import ShapeSpec
+    g = golden("norm_variants")["mask_head_" + norm]
+    cfg = get_cfg()
+    cfg.merge_from_file(config_path("centermask_V_39_eSE_FPN_ms_3x.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.ROI_MASK_HEAD.NORM", norm, "MODEL.ROI_MASK_HEAD.CONV_DIM", 128, "MODEL.ROI_MASK_HEAD.NUM_CONV", 2])
+    head = SpatialAttentionMaskHead(cfg, ShapeSpec(channels=128, width=14, height=14)).eval()
+    missing, unexpected = head.load_state_dict(g["state_dict"], strict=True)
+    assert not missing and not unexpected
+    y = head.to(dev)(g["x"].to(dev))
+    torch.cuda.synchronize()
+    close_abs(y, g["logits"], 1e-3, "mask head NORM " + norm + " logits")
+
+
+@pytest.mark.parametrize("norm", ["GN", "FrozenBN"])
+def test_fpn_norm_variants_match_reference(dev, norm):
+    """MODEL.FPN.NORM (vovnet.py:550): the reference's backbone builder with a norm behind every FPN conv (d2's FPN and get_norm through the
+    build container's stand-ins: unpinned against a real detectron2, like the plain FPN) — p3..p7 within 1e-3 absolute."""
+    from centermask2_amd import synthetic as S
+    from centermask2_amd.config import get_cfg, config_path
+    from centermask2_amd.registry import BACKBONE_REGISTRY
+    from centermask2_amd.structures import ShapeSpec
+    g = golden("norm_variants")["fpn_" + norm]
+    cfg = get_cfg()
+    cfg.merge_from_file(config_path("centermask_V_39_eSE_FPN_ms_3x.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.FPN.NORM", norm])
+    bb = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, ShapeSpec(channels=3)).eval()
+    own = bb.state_dict()
+    assert set(k for k in own if k.startswith("fpn_") or k.startswith("top_block")) == set(g["keys"])
+    sd = S.make_synthetic_state_dict("V-39-eSE", 0)
+    sub = {k: sd["backbone." + k] for k in own if "backbone." + k in sd}
+    sub.update(g["norm_state"])
+    missing, unexpected = bb.load_state_dict(sub, strict=False)
+    assert not unexpected and all(m.endswith("num_batches_tracked") for m in missing), (missing, unexpected)
+    out = bb.to(dev)(g["x"].to(dev))
+    torch.cuda.synchronize()
+    for k in ("p3", "p4", "p5", "p6", "p7"):
+        close_abs(out[k], g[k], 1e-3, "FPN NORM " + norm + " " + k)
