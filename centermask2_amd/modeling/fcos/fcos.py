@@ -280,10 +280,10 @@ class LazyInstances(Instances):
 
     @property
     def _fields(self):
-        st = self.__dict__["_store"]
+        st = self.__dict__.get("_store")
         if st is None:
-            batch, i = self.__dict__["_cmk_lazy"]
-            st = batch.fields_of(i)
+            batch, i = self.__dict__.get("_cmk_lazy", (None, -1))       # absent while copy / pickle rebuild the object: no fields yet
+            st = batch.fields_of(i) if batch is not None else {}
             object.__setattr__(self, "_store", st)
         return st
 
@@ -295,7 +295,7 @@ class LazyInstances(Instances):
 
     def lazy_batch(self):
         """(LazyBatch, index) while the padded buffers still describe this object, else (None, -1)."""
-        return self.__dict__["_cmk_lazy"]
+        return self.__dict__.get("_cmk_lazy", (None, -1))
 
 
 def instances_from_padded(det: dict, image_sizes) -> List[Instances]:

@@ -372,6 +372,9 @@ def test_lazy_instances_between_the_plugins():
     assert tuple(insts[0].pred_masks.shape) == (3, 1, 28, 28) and tuple(insts[1].pred_masks.shape) == (0, 1, 28, 28)
     assert insts[0].has("mask_scores") and tuple(insts[1].mask_scores.shape) == (0,)
     assert type(insts[0][0:2]) is Instances and len(insts[0][0:2]) == 2
+    import copy
+    c = copy.copy(insts[1])                                             # copies behave like the original (materialised) object
+    assert len(c) == 0 and c.image_size == (8, 9) and c.has("pred_masks")
     insts[0].pred_classes = torch.zeros(3, dtype=torch.int64)            # a caller's own value: the padded buffers no longer describe it
     assert lazy_batch_of(insts) is None and torch.equal(insts[0].pred_classes, torch.zeros(3, dtype=torch.int64))
     # overflow: the capacity was too small -> resolve() re-runs the tail (and the ROI heads) through the callbacks
