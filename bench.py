@@ -282,6 +282,60 @@ def other_body_leg(body, dev, B, steps=5, warmup=2):
         ops._TUNED.update(saved)
 
 
+def split_gemm_leg(body, dev, B, ref_out, steps=20, warmup=3):
+    """OPT-IN path, reported beside `value`, never as it: the same step with the plain 1x1 convs (OSA aggregation convs, the mask head's deconv)
+    on the pointwise GEMM's bf16-split form (cmk.h tune_wm 10: every fp32 product rebuilt from three bf16 pieces per operand, six MFMA
+    products, fp32 accumulation — the error of an fp32 accumulation).  The detections are compared with the default
+    path's (`ref_out`): same counts, same labels in the same order, scores within 1e-4."""
+    from centermask2_amd import ops, synthetic as S
+    saved, saved_flag = dict(ops._TUNED), ops.ALLOW_SPLIT_BF16
+    try:
+        ops.ALLOW_SPLIT_BF16 = True
+        ops._TUNED.clear()
+        table = os.path.join(ROOT, "centermask2_amd", "tuned", "mi355x_{}_b{}_800x1280.json".format(body, B))
+        if os.path.exists(table):
+            ops.load_tuned(table)
+        moved = 0
+        for k, v in list(ops._TUNED.items()):
+            if k[0] == 1 and k[1] == 1 and k[6] == 0 and v[0] == 8 and len(v) == 3:        # plain 1x1, no residual / fused affine, no split-K
+                ops._TUNED[k] = (10, 32, 4)
+                moved += 1
+        model, _ = build(body, dev)                       # packs the split weights (ALLOW_SPLIT_BF16 is on)
+        x = S.make_synthetic_images(B, 800, 1280, seed0=1234).to(dev)
+        sizes = [(800, 1280)] * B
+        with torch.no_grad():
+            model.inference_padded(x, sizes)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model.inference_padded(x, sizes)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = model.inference_padded(x, sizes)
+            for _ in range(warmup):
+                graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                graph.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        same_counts = bool(torch.equal(out["counts"], ref_out["counts"]))
+        same_labels = bool(torch.equal(out["cls"], ref_out["cls"]))
+        score_diff = float((out["score"] - ref_out["score"]).abs().max())
+        return {"images_per_sec": round(steps * B / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
+                "convs_moved": moved, "dtype": "f32 results; the moved 1x1 convs multiply bf16 pieces (3 per fp32 operand, 6 products) and accumulate in f32",
+                "same_detection_counts": same_counts, "same_labels_same_order": same_labels, "max_score_diff_vs_default": score_diff,
+                "status": "opt-in (CMK_ALLOW_SPLIT_BF16=1 + a variant table naming tune 10/32/4); not used by `value`"}
+    finally:
+        ops.ALLOW_SPLIT_BF16 = saved_flag
+        ops._TUNED.clear()
+        ops._TUNED.update(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -478,6 +532,8 @@ def main():
                 result["plugin_api"] = plugin_api
             if args.body == "V-39-eSE" and world == 1 and not args.no_extras:
                 result["v99"] = other_body_leg("V-99-eSE", dev, B)
+            if world == 1 and not args.no_extras:
+                result["split_gemm"] = split_gemm_leg(args.body, dev, B, out)
             if cpu is not None:
                 result["cpu_baseline"] = cpu
                 result["ap_delta"] = ap

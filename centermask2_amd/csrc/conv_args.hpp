@@ -61,5 +61,7 @@ int launch_wino6(ConvArgs& a, int geo, hipStream_t st);
 int launch_wino6s(ConvArgs& a, int geo, hipStream_t st);
 // conv_pw.hip: 1x1 conv as a GEMM with the weights fetched straight into registers; mt = 4 | 2 accumulator rows per wave
 int launch_pw(ConvArgs& a, int mt, hipStream_t st);
+// conv_pw.hip, opt-in: the same GEMM from bf16-split products (fp32-accurate; a.w = the split packing, cmk.h w_split)
+int launch_pw_split(ConvArgs& a, hipStream_t st);
 
 }  // namespace cmk

@@ -41,8 +41,17 @@ __device__ f32x4 pw_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) _
 // even output width (then the pixel pairs the epilogue handles share one residual pixel).
 // SPLITK: blockIdx.y owns an (even) range of the K chunks and leaves raw partial sums in a.ws[z][pixel][cout_pad]; the caller runs
 // conv_igemm's reduce kernel (scale/shift/residual/ReLU there).  For the skinny GEMMs: MaskIoU fc1 (400 x 12544 x 1024), the 14 -> 7 conv.
-template <int MT, bool POOL, bool GA, bool UPRES, bool SPLITK>
+// SPLIT (opt-in, cmk.h tune_wm 10; MT 4, no GA / UPRES / SPLITK): the same GEMM with fp32-ACCURATE products built from bf16 pieces on
+// v_mfma_f32_32x32x16_bf16 (2.0 PFLOP/s against the fp32 instruction's 0.157): every fp32 operand is split into three bf16 values
+// (x = hi + mid + lo exactly to 2^-24: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest even) and the six products of
+// weight >= 2^-16 — lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, small terms first — are accumulated in fp32.  Measured error against float64:
+// that of a sequential fp32 fma chain (tools/probe/gemm_split_bf16.hip, tools/split_bf16_numerics.py).  The activations stay fp32 in HBM
+// and are split while they are staged (global -> registers -> split -> LDS as [32-row block][piece][lane][8 bf16], the MFMA's A operand
+// layout: one ds_read_b128 per piece and block); the weights are split once on the host (a.w: [K/16][cout_pad/32][piece 3][lane 64][8 bf16]).
+// The accumulator layout is the fp32 kernel's, so the epilogue (scale/shift/ReLU, stores, POOL sums) is shared.
+template <int MT, bool POOL, bool GA, bool UPRES, bool SPLITK, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
+    static_assert(!SPLIT || (MT == 4 && !GA && !UPRES && !SPLITK), "the split form is the plain 256 x 128 tile");
     constexpr int BM = 64 * MT;         // pixels per workgroup
     constexpr int ABUF = BM * PST;      // floats per LDS buffer (rows of 16 channels, pitch 20)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -124,50 +133,6 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
         for (int it = 0; it < MT; ++it) *reinterpret_cast<f32x4*>(dst + it * 64 * PST) = a_st[it];
     };
 
-    // ---- weights: L2 -> registers; lane (li, hh) takes channels 8*hh .. 8*hh+7 of output channel (tile base + li) ---------------------
-    const float* wbase[2];
-#pragma unroll
-    for (int nn = 0; nn < 2; ++nn) wbase[nn] = a.w + (long)min(co0 + nn * 32, a.cout_pad - 32) * 16;     // wave-uniform
-    const long w_chunk = (long)a.cout_pad * 16;
-    const unsigned w_lane = li * 16 + hh * 8;
-    f32x4 bq[2][2][2];                  // [register set][cout tile][k-steps 0..3 | 4..7]
-    auto load_B = [&](int chunk, int set) {
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-            const float* src = wbase[nn] + chunk * w_chunk;
-            bq[set][nn][0] = *reinterpret_cast<const f32x4*>(src + w_lane);
-            bq[set][nn][1] = *reinterpret_cast<const f32x4*>(src + (w_lane + 4));
-        }
-    };
-
-    // ---- MFMA side --------------------------------------------------------------------------------------------------------------------
-    int a_off[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) a_off[m] = ((wm * MT + m) * 32 + li) * PST + hh * 8;
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
-    f32x4 avA[MT], avB[MT];             // operands of the first / second half (4 k-steps each) of a chunk
-    auto rd = [&](f32x4 (&v)[MT], int buf, int h) {
-        const float* A = smem + buf * ABUF + 4 * h;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) v[m] = *reinterpret_cast<const f32x4*>(A + a_off[m]);
-    };
-    // 4 k-steps: channels 4h..4h+3 (lane half 0) and 8+4h..8+4h+3 (lane half 1) of the chunk — conv_igemm's order
-    auto mh = [&](const f32x4 (&v)[MT], int set, int h) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[m][s], bq[set][nn][h][s], acc[m][nn], 0, 0, 0);
-    };
-
 #ifdef PW_TRACE
     // instrumented build (tools/ab/trace_pw.py): lane 0 of every wave of every 16th workgroup stamps the shader clock into LDS (a global
     // store inside the loop would make every barrier drain the loads in flight) and copies the stamps to a.ws at the end:
@@ -210,6 +175,128 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
 #else
 #define PW_STORE_A(b) store_A(b)
 #endif
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+    if constexpr (SPLIT) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        constexpr int STAGE = (BM / 32) * 3 * 64 * 16;          // bytes per LDS stage: [row block][piece][lane][8 bf16]
+        unsigned char* sb = reinterpret_cast<unsigned char*>(smem);
+        auto pk = [](float x, float y) { unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+        auto f_lo = [](unsigned p_) { return __builtin_bit_cast(float, p_ << 16); };
+        auto f_hi = [](unsigned p_) { return __builtin_bit_cast(float, p_ & 0xffff0000u); };
+        // this thread's 8-byte half slots: row r = tid / 4 + 64 it -> (block r / 32, li = r % 32); quad tid & 3 -> lane half (tid & 3) / 2, half slot (tid & 3) & 1
+        int st_off[MT];
+#pragma unroll
+        for (int it = 0; it < MT; ++it) {
+            const int r = (tid >> 2) + 64 * it;
+            st_off[it] = (((r >> 5) * 3) * 64 + ((tid & 3) >> 1) * 32 + (r & 31)) * 16 + (tid & 1) * 8;
+        }
+        auto stage = [&](int buf) {
+            unsigned char* dst = sb + buf * STAGE;
+#pragma unroll
+            for (int it = 0; it < MT; ++it) {
+                const f32x4 x = a_st[it];
+                u32x2 h, m_, l;
+                h.x = pk(x.x, x.y); h.y = pk(x.z, x.w);
+                const f32x4 r1 = {x.x - f_lo(h.x), x.y - f_hi(h.x), x.z - f_lo(h.y), x.w - f_hi(h.y)};
+                m_.x = pk(r1.x, r1.y); m_.y = pk(r1.z, r1.w);
+                const f32x4 r2 = {r1.x - f_lo(m_.x), r1.y - f_hi(m_.x), r1.z - f_lo(m_.y), r1.w - f_hi(m_.y)};
+                l.x = pk(r2.x, r2.y); l.y = pk(r2.z, r2.w);
+                *reinterpret_cast<u32x2*>(dst + st_off[it]) = h;
+                *reinterpret_cast<u32x2*>(dst + st_off[it] + 64 * 16) = m_;
+                *reinterpret_cast<u32x2*>(dst + st_off[it] + 2 * 64 * 16) = l;
+            }
+        };
+        const u32x4* wsp = reinterpret_cast<const u32x4*>(a.w) + ((long)(co0 >> 5) * 3) * 64 + lane;      // wave-uniform base + lane
+        const long wstep = (long)(a.cout_pad >> 5) * 3 * 64;
+        u32x4 wb[2][3];
+        auto load_Bs = [&](int chunk) {
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int p_ = 0; p_ < 3; ++p_) wb[nn][p_] = wsp[chunk * wstep + (nn * 3 + p_) * 64];
+        };
+        load_A(0);
+        load_Bs(0);
+        stage(0);
+        load_A(min(1, nchunks - 1));
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();            // stage c & 1 is complete; everybody has read all of the other stage
+            const u32x4* ap = reinterpret_cast<const u32x4*>(sb + (c & 1) * STAGE) + (wm * MT * 3) * 64 + lane;
+            u32x4 wc[2][3];
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int p_ = 0; p_ < 3; ++p_) wc[nn][p_] = wb[nn][p_];
+            load_Bs(min(c + 1, nchunks - 1));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const u32x4 ah = ap[(m * 3 + 0) * 64], am = ap[(m * 3 + 1) * 64], al = ap[(m * 3 + 2) * 64];
+                if (m == 1) {           // the next chunk's activations (in registers since the last chunk) are split between the MFMA groups
+                    stage((c + 1) & 1);
+                    load_A(min(c + 2, nchunks - 1));
+                }
+                const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    const bf16x8 Bh = __builtin_bit_cast(bf16x8, wc[nn][0]), Bm = __builtin_bit_cast(bf16x8, wc[nn][1]), Bl = __builtin_bit_cast(bf16x8, wc[nn][2]);
+                    f32x16 cacc = acc[m][nn];
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, cacc, 0, 0, 0);
+                    acc[m][nn] = cacc;
+                }
+            }
+        }
+        __syncthreads();                // the epilogue may reuse the LDS
+    } else {
+    // ---- weights: L2 -> registers; lane (li, hh) takes channels 8*hh .. 8*hh+7 of output channel (tile base + li) ---------------------
+    const float* wbase[2];
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) wbase[nn] = a.w + (long)min(co0 + nn * 32, a.cout_pad - 32) * 16;     // wave-uniform
+    const long w_chunk = (long)a.cout_pad * 16;
+    const unsigned w_lane = li * 16 + hh * 8;
+    f32x4 bq[2][2][2];                  // [register set][cout tile][k-steps 0..3 | 4..7]
+    auto load_B = [&](int chunk, int set) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+            const float* src = wbase[nn] + chunk * w_chunk;
+            bq[set][nn][0] = *reinterpret_cast<const f32x4*>(src + w_lane);
+            bq[set][nn][1] = *reinterpret_cast<const f32x4*>(src + (w_lane + 4));
+        }
+    };
+
+    // ---- MFMA side --------------------------------------------------------------------------------------------------------------------
+    int a_off[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_off[m] = ((wm * MT + m) * 32 + li) * PST + hh * 8;
+    f32x4 avA[MT], avB[MT];             // operands of the first / second half (4 k-steps each) of a chunk
+    auto rd = [&](f32x4 (&v)[MT], int buf, int h) {
+        const float* A = smem + buf * ABUF + 4 * h;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) v[m] = *reinterpret_cast<const f32x4*>(A + a_off[m]);
+    };
+    // 4 k-steps: channels 4h..4h+3 (lane half 0) and 8+4h..8+4h+3 (lane half 1) of the chunk — conv_igemm's order
+    auto mh = [&](const f32x4 (&v)[MT], int set, int h) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[m][s], bq[set][nn][h][s], acc[m][nn], 0, 0, 0);
+    };
+
     // ---- pipeline ------------------------------------------------------------------------------------------------------------------
     // chunk c, LDS buffer u = c & 1, weight set u:
     //   read the second-half operands of chunk c; 32 MFMAs of the first half, among them: A(c+1) (in registers since chunk c-1) into
@@ -255,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
         }
     }
 
+    }       // fp32-MFMA operand path
     PW_STAMP(58);
     // ---- epilogue: scale/shift (+same-size residual) (+ReLU), NHWC stores ------------------------------------------------------------------------
     // accumulator register r of lane half hh is pixel row (r & 3) + 8 * (r >> 2) + 4 * hh of the 32-pixel sub-tile; the lane is the cout
@@ -413,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int MT, bool POOL, bool GA, bool UPRES = false, bool SPLITK = false>
+template <int MT, bool POOL, bool GA, bool UPRES = false, bool SPLITK = false, bool SPLIT = false>
 static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * MT;
 #ifdef PW_TRACE
@@ -423,12 +511,12 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int LDS_BYTES = 2 * BM * PST * 4 + 4 * 64 * 8 + PW_LDS_EXTRA;      // PW_LDS_EXTRA: experiments with one workgroup per CU
     static DeviceOnce once;
     int rc0 = once.run([]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT, POOL, GA, UPRES, SPLITK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<MT, POOL, GA, UPRES, SPLITK, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_pw: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     });
     if (rc0) return rc0;
 #else
-    constexpr int LDS_BYTES = 2 * BM * PST * 4;       // 40 KB (MT 4) / 20 KB (MT 2): under the 64 KB a kernel gets without an attribute
+    constexpr int LDS_BYTES = SPLIT ? 2 * (BM / 32) * 3 * 64 * 16 : 2 * BM * PST * 4;       // 40 KB (MT 4) / 20 KB (MT 2) / 48 KB (split): under the 64 KB a kernel gets without an attribute
 #endif
     ConvProblem& p = a.p[0];
     p.tile_begin = 0;
@@ -436,7 +524,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     const long tiles = (p.total_pix + BM - 1) / BM;
     a.total_tiles = (int)tiles;
     a.grid_y = a.cout_pad / 128;
-    hipLaunchKernelGGL((conv_pw_kernel<MT, POOL, GA, UPRES, SPLITK>), dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y), SPLITK ? a.ksplit : 1), dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_pw_kernel<MT, POOL, GA, UPRES, SPLITK, SPLIT>), dim3((unsigned)(((tiles + 7) / 8) * 8 * a.grid_y), SPLITK ? a.ksplit : 1), dim3(256), LDS_BYTES, st, a);
     return check_launch("conv_pw");
 }
 
@@ -478,6 +566,18 @@ int launch_pw(ConvArgs& a, int mt, hipStream_t st) {
     if (mt == 4) return a.pool_ws ? launch_pw_mt<4, true, false>(a, st) : launch_pw_mt<4, false, false>(a, st);
     if (mt == 2) return a.pool_ws ? launch_pw_mt<2, true, false>(a, st) : launch_pw_mt<2, false, false>(a, st);
     return fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
+}
+
+// The bf16-split form (cmk.h tune_wm 10): a.w is the split packing; plain 1x1 conv, optionally with the pooled sums.
+int launch_pw_split(ConvArgs& a, hipStream_t st) {
+    const ConvProblem& p = a.p[0];
+    if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws || a.ksplit > 1 || a.res_mode != 0 || a.ga_stride)
+        return fail(CMK_EINVAL, "conv_pw (split): one plain 1x1 problem: no input affine / input ReLU / GroupNorm statistics / split-K / residual%s", "");
+    if ((a.Cin & 15) || (a.cout_pad & 127)) return fail(CMK_EINVAL, "conv_pw (split): needs Cin %% 16 == 0 and a cout padding of 128%s", "");
+    if (p.total_pix * a.x_cs * 4 >= (1L << 31)) return fail(CMK_EINVAL, "conv_pw (split): input view of 2 GiB or more%s", "");
+    if ((long)(64 * 4 + 8) * a.y_cs >= (1L << 30)) return fail(CMK_EINVAL, "conv_pw (split): output row too wide%s", "");
+    if (a.pool_ws && (long)p.Ho * p.Wo < 128) return fail(CMK_EINVAL, "conv_pw (split): pooled sums need H*W >= 128%s", "");
+    return a.pool_ws ? launch_pw_mt<4, true, false, false, false, true>(a, st) : launch_pw_mt<4, false, false, false, false, true>(a, st);
 }
 
 }  // namespace cmk

@@ -137,6 +137,28 @@ def pack_wino6_weight(w: torch.Tensor) -> torch.Tensor:
     return r.reshape(cin_pad // 8, nt, 4, 9, 64, 4)
 
 
+def pack_split_weight(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin[,1,1]) fp32 -> the bf16-split packing of cmk_conv_desc.w_split (opt-in tune_wm 10): every weight as three bf16 values
+    hi + mid + lo (round to nearest even, exact to 2^-24), laid out [Cin/16][cout_pad/32][piece][lane = 32*hh + li][8]:
+    input channel 16*chunk + 8*hh + e of output channel 32*tile + li; cout_pad = Cout rounded up to 128, zero filled."""
+    lib = _lib.load()
+    w2 = w.detach().float().cpu().reshape(w.shape[0], w.shape[1])
+    cout, cin = w2.shape
+    cin_pad, cout_pad = (cin + 15) // 16 * 16, (cout + 127) // 128 * 128
+    full = torch.zeros((cout_pad, cin_pad), dtype=torch.float32)
+    full[:cout, :cin] = w2
+    pieces, rest = [], full
+    for _ in range(3):
+        p = rest.to(torch.bfloat16)
+        pieces.append(p)
+        rest = rest - p.float()
+    st = torch.stack(pieces, 0)                                                    # (3, cout_pad, cin_pad)
+    r = st.reshape(3, cout_pad // 32, 32, cin_pad // 16, 2, 8)                      # [piece][tile][li][chunk][hh][e]
+    r = r.permute(3, 1, 0, 4, 2, 5).contiguous()                                   # [chunk][tile][piece][hh][li][e]
+    assert r.numel() == lib.cmk_split_packed_halves(cout, cin_pad)
+    return r.reshape(cin_pad // 16, cout_pad // 32, 3, 64, 8)
+
+
 class PackedConv:
     """Device-resident packed weights + per-channel epilogue (scale, shift) of one conv / linear layer."""
 
@@ -151,6 +173,8 @@ class PackedConv:
         self.w_wino = pack_wino_weight(weight).to(device) if (self.k == 3 and stride == 1 and self.cin >= 16) else None
         # F(4x4,3x3) weights: 4x the 3x3 filter bank; packed for every conv that can use them (PACK_WINO6 = False skips it)
         self.w_wino6 = pack_wino6_weight(weight).to(device) if (PACK_WINO6 and self.k == 3 and stride == 1 and self.cin >= 32) else None
+        # opt-in (ALLOW_SPLIT_BF16): the bf16-split packing for the pointwise GEMM's fp32-accurate split form (cmk.h tune_wm 10)
+        self.w_split = pack_split_weight(weight).to(device) if (ALLOW_SPLIT_BF16 and self.k == 1 and self.cout > 224 and self.cin_pad % 32 == 0) else None
         self.scale = (torch.ones(self.cout) if scale is None else scale.detach().float().cpu()).contiguous().to(device)
         self.shift = (torch.zeros(self.cout) if shift is None else shift.detach().float().cpu()).contiguous().to(device)
 
@@ -169,6 +193,7 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
     d.w = pc.w.data_ptr()
     d.w_wino = pc.w_wino.data_ptr() if getattr(pc, "w_wino", None) is not None else None
     d.w_wino6 = pc.w_wino6.data_ptr() if getattr(pc, "w_wino6", None) is not None else None
+    d.w_split = pc.w_split.data_ptr() if getattr(pc, "w_split", None) is not None else None
     d.scale, d.shift = pc.scale.data_ptr(), pc.shift.data_ptr()
     if res is not None:
         d.res, d.res_cs, d.res_co = res.t.data_ptr(), res.cs, res.co
@@ -195,6 +220,8 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
 # ---- tile-variant autotuning (host side; the library itself stays stateless) -----------------------------------
 FUSE_POOL = os.environ.get("CMK_FUSE_POOL", "1") != "0"      # eSE: average-pool partial sums from the aggregation conv's epilogue (A/B switch)
 PAIR_TOWERS = os.environ.get("CMK_PAIR_TOWERS", "1") != "0"  # FCOS head: conv k of the cls and the bbox tower in one launch (A/B switch)
+ALLOW_SPLIT_BF16 = os.environ.get("CMK_ALLOW_SPLIT_BF16", "0") == "1"   # OPT-IN: pack the bf16-split weights and let the tuner / tables use the
+                          # pointwise GEMM's split form (fp32-accurate products from bf16 pieces, cmk.h tune_wm 10).  Off: nothing in the package uses it.
 PACK_WINO6 = True         # pack the F(4x4,3x3) weights too (4x the filter bank per 3x3 stride-1 conv)
 ALLOW_WINOGRAD = True     # let the tuner pick the Winograd F(2x2,3x3) kernel where it is faster (fp32, differs by rounding only)
 FORCE_VARIANT = None      # (wm, sc, wn[, splitk]) for every conv launched through the wrappers below (tests, A/B tools); None = table/tuner/default
@@ -237,6 +264,8 @@ def _variant_on_menu(tv) -> bool:
     sk = tv[3] if len(tv) > 3 else 1
     if wm == 6 and sc == 64:          # F(4x4,3x3), shared-V form (conv_wino6s.hip)
         return wn in (1, 2) and sk == 1
+    if wm == 10:                      # pointwise GEMM from bf16-split products: only where the caller opted in
+        return ALLOW_SPLIT_BF16 and sc == 32 and wn == 4 and sk == 1
     return (wm in (1, 2, 5, 6, 7, 8, 9) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
 
 
@@ -297,6 +326,8 @@ def _tune(descs, n, key) -> None:
         cands += [(9, 32, mt, sk) for mt in (4, 2) for sk in sks]   # gather form of a 3x3 conv on the pointwise GEMM kernel (conv_pw.hip GA)
     if d0.ksize == 1:
         cands += [(8, 32, mt, sk) for mt in (4, 2) for sk in sks]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
+        if ALLOW_SPLIT_BF16:
+            cands += [(10, 32, 4, 1)]                               # ... its opt-in bf16-split form (the library refuses it where it does not apply)
     if ALLOW_WINOGRAD:
         cands += [(5, 16, 2, 1)]                  # fused Winograd F(2x2,3x3)
         cands += [(6, 16, 1, 1), (6, 16, 2, 1)]   # fused Winograd F(4x4,3x3): map tiles / pairs of RoI maps (the library rejects what does not apply)
@@ -859,7 +890,7 @@ def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) 
         wgs = sum(cd(n, 2) for n, h, w in shapes) if wn == 2 else sum(n * cd(h, 12) * cd(w, 40) for n, h, w in shapes)
         return float(wgs * cd(cout, 32) * (cin_pad // 8) * 144 * 4096)
     cout_pad = _lib.load().cmk_conv_cout_pad(cout)
-    if wm in (8, 9):      # workgroup = 64*wn pixels x 128 couts; 9 = the gather form (K = 9 taps x Cin)
+    if wm in (8, 9, 10):  # workgroup = 64*wn pixels x 128 couts; 9 = the gather form (K = 9 taps x Cin); 10 = the split form, priced in fp32-equivalent FLOPs
         return float(sum(cd(n * h * w, 64 * wn) for n, h, w in shapes)) * (64 * wn) * (cd(cout, 128) * 128) * cin_pad * taps * 2.0
     if wm not in (1, 2):                      # cost-model / gather / split-K variants: geometry of the smallest tile
         wm, sc = 1, (32 if taps == 1 else 16)
@@ -884,9 +915,11 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False) -> str:
     wm, sc, wn = tv[:3]
     sk = "true" if (len(tv) > 3 and tv[3] > 1) else "false"
     if wm == 8:
-        return "conv_pw_kernel<{}, {}, false, {}, {}>".format(wn, "true" if pool else "false", "true" if upres else "false", sk)
+        return "conv_pw_kernel<{}, {}, false, {}, {}, false>".format(wn, "true" if pool else "false", "true" if upres else "false", sk)
+    if wm == 10:
+        return "conv_pw_kernel<4, {}, false, false, false, true>".format("true" if pool else "false")
     if wm == 9:
-        return "conv_pw_kernel<{}, false, true, false, {}>".format(wn, sk)
+        return "conv_pw_kernel<{}, false, true, false, {}, false>".format(wn, sk)
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)
     return "conv_igemm_kernel<{}, {}, {}, {}, {}, false>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)

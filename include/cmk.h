@@ -24,8 +24,8 @@ extern "C" {
 #define CMK_EINVAL (-1)   /* bad argument / unsupported shape */
 #define CMK_ELAUNCH (-2)  /* HIP launch error */
 
-int cmk_version(void);                 /* ABI version, currently 3 (2: cmk_conv_desc.w_wino6, cmk_groupnorm_affine_tiles takes record counts;
-                                          3: cmk_conv_desc.pool_ws, cmk_ese_gate_pooled, cmk_pack_records); additions since keep 3 */
+int cmk_version(void);                 /* ABI version, currently 4 (2: cmk_conv_desc.w_wino6, cmk_groupnorm_affine_tiles takes record counts;
+                                          3: cmk_conv_desc.pool_ws, cmk_ese_gate_pooled, cmk_pack_records; 4: cmk_conv_desc.w_split) */
 const char* cmk_arch(void);            /* "gfx950" */
 const char* cmk_last_error(void);
 
@@ -105,6 +105,15 @@ typedef struct {
      * of block g (pixels gR .. gR+R-1) that belong to the image of the block's first pixel, record 2g+1 = the sum over its rows that
      * belong to the next image (0 if none); every record is written.  cmk_ese_gate_pooled turns them into the gate.  NULL = off. */
     float* pool_ws;
+    /* OPT-IN, tune_wm == 10 (tune_sc 32, tune_wn 4): a plain 1x1 conv (Cin % 16 == 0, Cout > 224 or 97..128, no residual / input affine / split-K;
+     * pool_ws allowed) as the same GEMM with every fp32 product rebuilt from bf16 pieces on v_mfma_f32_32x32x16_bf16: x = hi + mid + lo with
+     * hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (round to nearest even; exact to 2^-24), the six products of weight >= 2^-16
+     * accumulated in fp32.  The result carries the error of an fp32 accumulation (measured: that of a sequential fp32 fma chain), NOT the bits
+     * of the fp32-MFMA kernels.  The activations are fp32 and are split inside the kernel; the weights are split by the caller:
+     * w_split = cmk_split_packed_halves(Cout, Cin) 16-bit values, [Cin/16][cout_pad/32][piece hi|mid|lo][lane 64][8], lane = 32*hh + li holding
+     * input channels 16*chunk + 8*hh + 0..7 of output channel 32*tile + li (cout_pad = Cout rounded up to 128, zero filled).
+     * No caller of this repository selects it by default (ops.ALLOW_SPLIT_BF16); NULL = not available. */
+    const void* w_split;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
 int cmk_conv_pool_rows(const cmk_conv_desc* d);
@@ -121,6 +130,7 @@ int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize);
 int cmk_conv_cout_pad(int Cout);
 int64_t cmk_wino_packed_floats(int Cout, int Cin);
 int64_t cmk_wino6_packed_floats(int Cout, int Cin);
+int64_t cmk_split_packed_halves(int Cout, int Cin);          /* 16-bit elements of cmk_conv_desc.w_split */
 /* spatial tiles per image of the fused-statistics conv (8 x 16 outputs each) */
 int cmk_conv_gn_tiles(int H, int W);
 /* {sum, sumsq} records per image written through cmk_conv_desc.gn_ws by the Winograd kernel tune_wm (5 or 6) on an H x W map */

@@ -644,6 +644,55 @@ def test_tower_pair_launch_equals_two_launches(dev, sc, with_affine, monkeypatch
     assert ops.conv_gn_multi_pair(xs, pca, gn[0], xs, pcb, gn[1], groups, 1e-5) is None
 
 
+@pytest.mark.parametrize("case", [(2, 13, 19, 96, 256, False), (1, 25, 40, 2144, 1024, True), (1, 16, 16, 64, 320, False), (1, 64, 64, 768, 256, True),
+                                  (2, 10, 13, 160, 512, True)])
+def test_conv_pointwise_split_bf16_form(dev, case, monkeypatch):
+    """OPT-IN tune_wm 10: the pointwise GEMM with every fp32 product rebuilt from three bf16 pieces per operand (six products, fp32
+    accumulation) — checked against a FLOAT64 convolution at 2e-5 absolute (the fp32-MFMA kernel's own distance from float64 on these
+    shapes), ragged pixel counts, cout padding, channel views via the packed conv, and the pooled sums of the eSE gate; refused without
+    the split packing."""
+    import ctypes
+    from centermask2_amd import _lib
+    n, h, w, cin, cout, pool = case
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16", True)
+    x = _rand((n, cin, h, w), 301).abs()                      # post-ReLU-like inputs
+    wt = _rand((cout, cin, 1, 1), 302, (2.0 / cin) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(303)) + 0.5
+    shift = _rand((cout,), 304, 0.1)
+    ref = F.relu(F.conv2d(x.double(), wt.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    pc = ops.PackedConv(wt, scale, shift, dev)
+    assert pc.w_split is not None
+    xv = ops.as_view(x.to(dev))
+    ys = {}
+    for tv in ((10, 32, 4), (8, 32, 4)):
+        y = View(torch.full((n, h, w, cout), -5.0, device=dev))
+        d = (_lib.ConvDesc * 1)()
+        ops._fill_desc(d[0], xv, pc, y, True, None, None, False, False)
+        d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = tv
+        pws = None
+        if pool:
+            rows = cmk_rows = _lib.load().cmk_conv_pool_rows(ctypes.byref(d[0]))
+            assert rows == 128
+            pws = torch.zeros((2 * (-(-(n * h * w) // rows)), cout), dtype=torch.float32, device=dev)
+            d[0].pool_ws = pws.data_ptr()
+        _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "pointwise " + str(tv))
+        torch.cuda.synchronize()
+        ys[tv[0]] = (y, pws)
+    err_split = float((ys[10][0].nchw().cpu().double() - ref).abs().max())
+    err_f32 = float((ys[8][0].nchw().cpu().double() - ref).abs().max())
+    assert err_split <= 2e-5 and err_split <= 4.0 * err_f32 + 1e-6, (err_split, err_f32)
+    if pool:                                                   # the same records (sums of the stored values) up to the values' own rounding
+        a, b = ys[10][1].cpu().double(), ys[8][1].cpu().double()
+        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
+    # without the split packing the variant is refused, not silently replaced
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16", False)
+    pc2 = ops.PackedConv(wt, scale, shift, dev)
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], xv, pc2, View(torch.empty((n, h, w, cout), device=dev)), True, None, None, False, False)
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 10, 32, 4
+    assert _lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
+
+
 def test_groupnorm_affine_multi_level(dev):
     shapes = [(100, 160), (13, 20), (7, 10), (1, 2)]
     gamma = torch.rand(256, generator=torch.Generator().manual_seed(42)) + 0.5

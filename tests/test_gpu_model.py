@@ -403,3 +403,53 @@ def test_fpn_norm_variants_match_reference(dev, norm):
     torch.cuda.synchronize()
     for k in ("p3", "p4", "p5", "p6", "p7"):
         close_abs(out[k], g[k], 1e-3, "FPN NORM " + norm + " " + k)
+
+
+def split_variant_table(body="V-39-eSE"):
+    """The shipped variant table with every eligible 1x1 conv (plain pointwise GEMM, no residual, no split-K) moved to the opt-in
+    bf16-split form (tune 10/32/4)."""
+    import json, os
+    from centermask2_amd import ops
+    from .helpers import GOLDEN_ROOT
+    path = os.path.join(os.path.dirname(GOLDEN_ROOT), "centermask2_amd", "tuned", "mi355x_{}_b8_800x1280.json".format(body))
+    table = json.load(open(path))
+    out = {}
+    for k, v in table.items():
+        if k.startswith("k1s1") and "_res0_" in k and v[0] == 8 and len(v) == 3:
+            v = [10, 32, 4]
+        out[ops._str_to_key(k)] = tuple(v)
+    return out
+
+
+def test_end_to_end_batch8_with_the_opt_in_split_gemm(dev, monkeypatch):
+    """OPT-IN path (ops.ALLOW_SPLIT_BF16; nothing selects it by default): the 1x1 aggregation convs, the mask head's deconv-as-1x1 as GEMMs
+    whose fp32 products are rebuilt from bf16 pieces (cmk.h tune_wm 10).  The same gate as the default path: all eight bench images
+    against the reference's fixture — labels, ROI locations and their ORDER exact, features / logits / scores / masks within 1e-3 absolute."""
+    from centermask2_amd import ops, synthetic as S
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16", True)
+    model = build_gpu_model()[0]                      # packs the split weights
+    g = golden("e2e_bench8_800x1280")
+    B = int(g["num_images"])
+    saved = dict(ops._TUNED)
+    try:
+        ops._TUNED.clear()
+        ops._TUNED.update(split_variant_table())
+        assert sum(1 for v in ops._TUNED.values() if v[0] == 10) >= 6
+        x = S.make_synthetic_images(B, 800, 1280, seed0=int(g["image_seed0"])).to(dev)
+        sizes = [(800, 1280)] * B
+        out = model.inference_padded(x, sizes)
+        feats = model.backbone(x)
+        lg, reg, ctr, _ = model.proposal_generator.fcos_head([feats[k] for k in ("p3", "p4", "p5", "p6", "p7")])
+        torch.cuda.synchronize()
+        res = model.results_from_padded(out, sizes)
+        for i in range(B):
+            r = g["img{}".format(i)]
+            for k in ("p3", "p4", "p5", "p6", "p7"):
+                _probe_check(feats[k][i:i + 1], r[k], 1e-3, "split-gemm " + k)
+            for l in range(5):
+                _probe_check(lg[l][i:i + 1], r["logits{}".format(l)], 1e-3, "split-gemm logits")
+                _probe_check(reg[l][i:i + 1], r["reg{}".format(l)], 1e-3, "split-gemm reg")
+            _check_against_reference_image(res[i], r, "split-gemm image {}".format(i), ORDER_TOL)
+    finally:
+        ops._TUNED.clear()
+        ops._TUNED.update(saved)
