@@ -283,8 +283,8 @@ def other_body_leg(body, dev, B, steps=5, warmup=2):
 
 
 def split_gemm_leg(body, dev, B, ref_out, steps=20, warmup=3):
-    """OPT-IN path, reported beside `value`, never as it: the same step with the plain 1x1 convs (OSA aggregation convs, the mask head's deconv)
-    on the pointwise GEMM's bf16-split form (cmk.h tune_wm 10: every fp32 product rebuilt from three bf16 pieces per operand, six MFMA
+    """OPT-IN path, reported beside `value`, never as it: the same step with the convs the pointwise GEMM kernel runs (OSA aggregation convs, FPN
+    laterals, the mask head's deconv, stem_3 in the gather form) on its bf16-split form (cmk.h tune_wm 10: every fp32 product rebuilt from three bf16 pieces per operand, six MFMA
     products, fp32 accumulation — the error of an fp32 accumulation).  The detections are compared with the default
     path's (`ref_out`): same counts, same labels in the same order, scores within 1e-4."""
     from centermask2_amd import ops, synthetic as S
@@ -297,7 +297,8 @@ def split_gemm_leg(body, dev, B, ref_out, steps=20, warmup=3):
             ops.load_tuned(table)
         moved = 0
         for k, v in list(ops._TUNED.items()):
-            if k[0] == 1 and k[1] == 1 and k[6] == 0 and v[0] == 8 and len(v) == 3:        # plain 1x1, no residual / fused affine, no split-K
+            # every conv the pointwise GEMM kernel runs without split-K: plain 1x1 (8), 1x1 with the FPN top-down add (8, res 2), 3x3 in the gather form (9)
+            if len(v) == 3 and ((k[0] == 1 and v[0] == 8 and k[6] in (0, 2)) or (k[0] == 3 and v[0] == 9 and k[6] == 0)):
                 ops._TUNED[k] = (10, 32, 4)
                 moved += 1
         model, _ = build(body, dev)                       # packs the split weights (ALLOW_SPLIT_BF16 is on)
@@ -327,7 +328,7 @@ def split_gemm_leg(body, dev, B, ref_out, steps=20, warmup=3):
         same_labels = bool(torch.equal(out["cls"], ref_out["cls"]))
         score_diff = float((out["score"] - ref_out["score"]).abs().max())
         return {"images_per_sec": round(steps * B / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
-                "convs_moved": moved, "dtype": "f32 results; the moved 1x1 convs multiply bf16 pieces (3 per fp32 operand, 6 products) and accumulate in f32",
+                "convs_moved": moved, "dtype": "f32 results; the moved convs multiply bf16 pieces (3 per fp32 operand, 6 products per fp32 product) and accumulate in f32",
                 "same_detection_counts": same_counts, "same_labels_same_order": same_labels, "max_score_diff_vs_default": score_diff,
                 "status": "opt-in (CMK_ALLOW_SPLIT_BF16=1 + a variant table naming tune 10/32/4); not used by `value`"}
     finally:

@@ -906,7 +906,7 @@ static int pointwise_mt(const cmk_conv_desc* d, int n) {
     if (d->splitk > 1 && (d->tune_wm != 8 || !d->splitk_ws || d->res_mode == 2 || d->pool_ws || (d->Cin >> 4) % (2 * d->splitk))) return 0;
     if (d->res_mode == 2 && ((d->W & 1) || d->pool_ws || (long)d->N * d->Hr * d->Wr * d->res_cs * 4 >= (1L << 31))) return 0;     // FPN top-down add: even widths
     if (d->tune_wm == 8) return (d->tune_wn == 4 || d->tune_wn == 2) ? d->tune_wn : 0;
-    if (d->tune_wm == 10) return (d->w_split && d->tune_wn == 4 && d->res_mode == 0 && d->splitk <= 1) ? 4 : 0;      // the bf16-split form: the 256-pixel tile
+    if (d->tune_wm == 10) return (d->w_split && d->tune_wn == 4 && d->res_mode != 1 && d->splitk <= 1) ? 4 : 0;      // the bf16-split form: the 256-pixel tile
     if (d->tune_wm || d->tune_sc || d->tune_wn) return 0;
     const long ctiles = cdiv(cout32, 4);
     const long wg2 = ((total_pix + 127) / 128) * ctiles, wg4 = ((total_pix + 255) / 256) * ctiles;
@@ -924,6 +924,7 @@ static int gather_mt(const cmk_conv_desc* d, int n) {
         return 0;
     if (d->splitk > 1 && (d->tune_wm != 9 || !d->splitk_ws || (9 * (d->Cin >> 4)) % (2 * d->splitk))) return 0;
     if (d->tune_wm == 9) return (d->tune_wn == 4 || d->tune_wn == 2) ? d->tune_wn : 0;
+    if (d->tune_wm == 10) return (d->w_split && d->tune_wn == 4 && d->res_mode == 0 && d->splitk <= 1) ? 4 : 0;      // the bf16-split gather form
     if (d->tune_wm || d->tune_sc || d->tune_wn || d->stride != 2) return 0;
     const long ctiles = cdiv(cout32, 4);
     const long wg4 = ((out_pix + 255) / 256) * ctiles;
@@ -1003,10 +1004,12 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         return run_pointwise(a, d->tune_wn, st);
     }
     if (d->tune_wm == 10) {                            // opt-in: the pointwise GEMM from bf16-split products (fp32-accurate, cmk.h w_split)
-        if (!pointwise_mt(d, n)) return fail(CMK_EINVAL, "conv: the bf16-split pointwise variant needs a plain 1x1 conv with Cout > 224, Cin %% 32 == 0 and w_split%s", "");
+        if (!(d->ksize == 1 ? pointwise_mt(d, n) : gather_mt(d, n)))
+            return fail(CMK_EINVAL, "conv: the bf16-split variant needs w_split and a conv the pointwise GEMM kernel takes (1x1, or 3x3 in its gather form)%s", "");
         a.cout_pad = cdiv(cout32, 4) * 128;
         a.w = reinterpret_cast<const float*>(d->w_split);
         a.ksplit = 1;
+        a.ga_stride = d->ksize == 3 ? d->stride : 0;
         return launch_pw_split(a, st);
     }
     if (d->tune_wm == 9) {                             // gather form of a 3x3 conv on the pointwise GEMM kernel; tune_wn = accumulator rows per wave
@@ -1115,7 +1118,7 @@ extern "C" int cmk_conv_gn_records(int H, int W, int tune_wm) {
     return tune_wm == 6 ? 4 * ((H + 11) / 12) * ((W + 39) / 40) : 2 * ((H + 7) / 8) * ((W + 15) / 16);
 }
 
-extern "C" int64_t cmk_split_packed_halves(int Cout, int Cin) {
+extern "C" int64_t cmk_split_packed_halves(int Cout, int Cin) {      // per tap of the conv: a 3x3 conv in the gather form holds nine of these, tap-major
     return (int64_t)((Cin + 15) / 16) * (((Cout + 127) / 128) * 4) * 3 * 64 * 8;
 }
 

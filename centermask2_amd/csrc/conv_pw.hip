@@ -51,7 +51,7 @@ __device__ f32x4 pw_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) _
 // The accumulator layout is the fp32 kernel's, so the epilogue (scale/shift/ReLU, stores, POOL sums) is shared.
 template <int MT, bool POOL, bool GA, bool UPRES, bool SPLITK, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
-    static_assert(!SPLIT || (MT == 4 && !GA && !UPRES && !SPLITK), "the split form is the plain 256 x 128 tile");
+    static_assert(!SPLIT || (MT == 4 && !SPLITK && !(GA && (UPRES || POOL))), "the split form: the 256 x 128 tile, no split-K");
     constexpr int BM = 64 * MT;         // pixels per workgroup
     constexpr int ABUF = BM * PST;      // floats per LDS buffer (rows of 16 channels, pitch 20)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int p_ = 0; p_ < 3; ++p_) wb[nn][p_] = wsp[chunk * wstep + (nn * 3 + p_) * 64];
         };
+        // (GA: load_A walks the 9 taps x Cin / 16 chunks in order, re-pointing the rows per tap; the split weights are packed tap-major to match)
         load_A(0);
         load_Bs(0);
         stage(0);
@@ -571,11 +572,21 @@ int launch_pw(ConvArgs& a, int mt, hipStream_t st) {
 // The bf16-split form (cmk.h tune_wm 10): a.w is the split packing; plain 1x1 conv, optionally with the pooled sums.
 int launch_pw_split(ConvArgs& a, hipStream_t st) {
     const ConvProblem& p = a.p[0];
-    if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws || a.ksplit > 1 || a.res_mode != 0 || a.ga_stride)
-        return fail(CMK_EINVAL, "conv_pw (split): one plain 1x1 problem: no input affine / input ReLU / GroupNorm statistics / split-K / residual%s", "");
+    if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws || a.ksplit > 1 || a.res_mode == 1)
+        return fail(CMK_EINVAL, "conv_pw (split): one problem, no input affine / input ReLU / GroupNorm statistics / split-K / same-size residual%s", "");
     if ((a.Cin & 15) || (a.cout_pad & 127)) return fail(CMK_EINVAL, "conv_pw (split): needs Cin %% 16 == 0 and a cout padding of 128%s", "");
-    if (p.total_pix * a.x_cs * 4 >= (1L << 31)) return fail(CMK_EINVAL, "conv_pw (split): input view of 2 GiB or more%s", "");
-    if ((long)(64 * 4 + 8) * a.y_cs >= (1L << 30)) return fail(CMK_EINVAL, "conv_pw (split): output row too wide%s", "");
+    const long in_pix = a.ga_stride ? (long)p.N * p.H * p.W : p.total_pix;
+    if (in_pix * a.x_cs * 4 >= (1L << 31)) return fail(CMK_EINVAL, "conv_pw (split): input view of 2 GiB or more%s", "");
+    if ((long)(64 * 4 + 8) * a.y_cs >= (1L << 30) || (long)(64 * 4 + 8) * a.res_cs >= (1L << 30)) return fail(CMK_EINVAL, "conv_pw (split): output row too wide%s", "");
+    if (a.ga_stride) {              // 3x3 conv (stride 1 | 2) as the gather GEMM over 9 taps
+        if (a.pool_ws || a.res_mode || p.H >= 32768 || p.W >= 32768) return fail(CMK_EINVAL, "conv_pw (split): gather form: no pooled sums / residual, maps below 32768 x 32768%s", "");
+        return launch_pw_mt<4, false, true, false, false, true>(a, st);
+    }
+    if (a.res_mode == 2) {          // FPN top-down add in the epilogue
+        if (a.pool_ws || (p.Wo & 1) || (long)p.N * a.Hr * a.Wr * a.res_cs * 4 >= (1L << 31))
+            return fail(CMK_EINVAL, "conv_pw (split): the upsampled residual needs an even output width, no pooled sums, a residual below 2 GiB%s", "");
+        return launch_pw_mt<4, false, false, true, false, true>(a, st);
+    }
     if (a.pool_ws && (long)p.Ho * p.Wo < 128) return fail(CMK_EINVAL, "conv_pw (split): pooled sums need H*W >= 128%s", "");
     return a.pool_ws ? launch_pw_mt<4, true, false, false, false, true>(a, st) : launch_pw_mt<4, false, false, false, false, true>(a, st);
 }

@@ -142,7 +142,16 @@ def pack_split_weight(w: torch.Tensor) -> torch.Tensor:
     hi + mid + lo (round to nearest even, exact to 2^-24), laid out [Cin/16][cout_pad/32][piece][lane = 32*hh + li][8]:
     input channel 16*chunk + 8*hh + e of output channel 32*tile + li; cout_pad = Cout rounded up to 128, zero filled."""
     lib = _lib.load()
-    w2 = w.detach().float().cpu().reshape(w.shape[0], w.shape[1])
+    if w.dim() == 4 and w.shape[2] == 3:          # 3x3 conv in the gather form: K walks the taps (kh, kw) outermost, then the padded input channels
+        cout, cin = w.shape[0], w.shape[1]
+        cin_pad1 = (cin + 15) // 16 * 16
+        wk = torch.zeros((cout, 9, cin_pad1), dtype=torch.float32)
+        wk[:, :, :cin] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, 9, cin)
+        w2 = wk.reshape(cout, 9 * cin_pad1)
+        taps = 9
+    else:
+        w2 = w.detach().float().cpu().reshape(w.shape[0], w.shape[1])
+        taps = 1
     cout, cin = w2.shape
     cin_pad, cout_pad = (cin + 15) // 16 * 16, (cout + 127) // 128 * 128
     full = torch.zeros((cout_pad, cin_pad), dtype=torch.float32)
@@ -155,7 +164,7 @@ def pack_split_weight(w: torch.Tensor) -> torch.Tensor:
     st = torch.stack(pieces, 0)                                                    # (3, cout_pad, cin_pad)
     r = st.reshape(3, cout_pad // 32, 32, cin_pad // 16, 2, 8)                      # [piece][tile][li][chunk][hh][e]
     r = r.permute(3, 1, 0, 4, 2, 5).contiguous()                                   # [chunk][tile][piece][hh][li][e]
-    assert r.numel() == lib.cmk_split_packed_halves(cout, cin_pad)
+    assert r.numel() == taps * lib.cmk_split_packed_halves(cout, cin_pad // taps)
     return r.reshape(cin_pad // 16, cout_pad // 32, 3, 64, 8)
 
 
@@ -174,7 +183,8 @@ class PackedConv:
         # F(4x4,3x3) weights: 4x the 3x3 filter bank; packed for every conv that can use them (PACK_WINO6 = False skips it)
         self.w_wino6 = pack_wino6_weight(weight).to(device) if (PACK_WINO6 and self.k == 3 and stride == 1 and self.cin >= 32) else None
         # opt-in (ALLOW_SPLIT_BF16): the bf16-split packing for the pointwise GEMM's fp32-accurate split form (cmk.h tune_wm 10)
-        self.w_split = pack_split_weight(weight).to(device) if (ALLOW_SPLIT_BF16 and self.k == 1 and self.cout > 224 and self.cin_pad % 32 == 0) else None
+        self.w_split = pack_split_weight(weight).to(device) if (ALLOW_SPLIT_BF16 and self.cin_pad % 32 == 0 and (
+            (self.k == 1 and self.cout > 224) or (self.k == 3 and (self.cout > 224 or 96 < self.cout <= 128)))) else None
         self.scale = (torch.ones(self.cout) if scale is None else scale.detach().float().cpu()).contiguous().to(device)
         self.shift = (torch.zeros(self.cout) if shift is None else shift.detach().float().cpu()).contiguous().to(device)
 
@@ -324,6 +334,8 @@ def _tune(descs, n, key) -> None:
         cands += [(7, 32, wn, sk) for wn in (1, 2, 4) for sk in sks]      # gather form
     if d0.ksize == 3:
         cands += [(9, 32, mt, sk) for mt in (4, 2) for sk in sks]   # gather form of a 3x3 conv on the pointwise GEMM kernel (conv_pw.hip GA)
+        if ALLOW_SPLIT_BF16:
+            cands += [(10, 32, 4, 1)]                               # ... and its opt-in bf16-split form
     if d0.ksize == 1:
         cands += [(8, 32, mt, sk) for mt in (4, 2) for sk in sks]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
         if ALLOW_SPLIT_BF16:
@@ -917,7 +929,7 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False) -> str:
     if wm == 8:
         return "conv_pw_kernel<{}, {}, false, {}, {}, false>".format(wn, "true" if pool else "false", "true" if upres else "false", sk)
     if wm == 10:
-        return "conv_pw_kernel<4, {}, false, false, false, true>".format("true" if pool else "false")
+        return "conv_pw_kernel<4, {}, {}, {}, false, true>".format("true" if pool else "false", "true" if taps == 9 else "false", "true" if upres else "false")
     if wm == 9:
         return "conv_pw_kernel<{}, false, true, false, {}, false>".format(wn, sk)
     if wm == 7:

@@ -693,6 +693,44 @@ def test_conv_pointwise_split_bf16_form(dev, case, monkeypatch):
     assert _lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
 
 
+def test_conv_split_bf16_gather_and_upsampled_residual_forms(dev, monkeypatch):
+    """OPT-IN tune_wm 10 beyond the plain 1x1 conv: a 3x3 conv (stride 2 and stride 1) in the gather form — K walks 9 taps x Cin / 16 chunks, the split
+    weights packed tap-major — and a 1x1 lateral with the nearest-2x upsampled residual in the epilogue (d2 FPN top-down add); against float64."""
+    import ctypes
+    from centermask2_amd import _lib
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16", True)
+    for (n, h, w, cin, cout, stride) in ((2, 21, 35, 64, 128, 2), (1, 17, 23, 32, 256, 1)):
+        x = _rand((n, cin, h, w), 311).abs()
+        wt = _rand((cout, cin, 3, 3), 312, (2.0 / (cin * 9)) ** 0.5)
+        bias = _rand((cout,), 313, 0.1)
+        ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), stride=stride, padding=1))
+        pc = ops.PackedConv(wt, None, bias, dev, stride=stride)
+        assert pc.w_split is not None
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        y = View(torch.full((n, ho, wo, cout), -5.0, device=dev))
+        d = (_lib.ConvDesc * 1)()
+        ops._fill_desc(d[0], ops.as_view(x.to(dev)), pc, y, True, None, None, False, False)
+        d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 10, 32, 4
+        _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "split gather form")
+        torch.cuda.synchronize()
+        assert float((y.nchw().cpu().double() - ref).abs().max()) <= 2e-5
+    # lateral + nearest-2x upsampled residual
+    n, h, w, cin, cout = 2, 12, 20, 512, 256
+    x = _rand((n, cin, h, w), 321).abs()
+    wt = _rand((cout, cin, 1, 1), 322, (2.0 / cin) ** 0.5)
+    bias = _rand((cout,), 323, 0.1)
+    coarse = _rand((n, cout, h // 2, w // 2), 324)
+    ref = F.conv2d(x.double(), wt.double(), bias.double()) + F.interpolate(coarse.double(), scale_factor=2, mode="nearest")
+    pc = ops.PackedConv(wt, None, bias, dev)
+    y = View(torch.empty((n, h, w, cout), device=dev))
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], ops.as_view(x.to(dev)), pc, y, False, None, ops.as_view(coarse.to(dev)), True, False)
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 10, 32, 4
+    _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "split lateral + upsampled residual")
+    torch.cuda.synchronize()
+    assert float((y.nchw().cpu().double() - ref).abs().max()) <= 2e-5
+
+
 def test_groupnorm_affine_multi_level(dev):
     shapes = [(100, 160), (13, 20), (7, 10), (1, 2)]
     gamma = torch.rand(256, generator=torch.Generator().manual_seed(42)) + 0.5
