@@ -282,7 +282,7 @@ def other_body_leg(body, dev, B, steps=5, warmup=2):
         ops._TUNED.update(saved)
 
 
-def split_gemm_leg(body, dev, B, ref_out, steps=20, warmup=3):
+def split_gemm_leg(body, dev, B, ref_out=None, steps=20, warmup=3):
     """OPT-IN path, reported beside `value`, never as it: the same step with the convs the pointwise GEMM kernel runs (OSA aggregation convs, FPN
     laterals, the mask head's deconv, stem_3 in the gather form) on its bf16-split form (cmk.h tune_wm 10: every fp32 product rebuilt from three bf16 pieces per operand, six MFMA
     products, fp32 accumulation — the error of an fp32 accumulation).  The detections are compared with the default
@@ -324,10 +324,12 @@ def split_gemm_leg(body, dev, B, ref_out, steps=20, warmup=3):
                 graph.replay()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        same_counts = bool(torch.equal(out["counts"], ref_out["counts"]))
-        same_labels = bool(torch.equal(out["cls"], ref_out["cls"]))
-        score_diff = float((out["score"] - ref_out["score"]).abs().max())
-        return {"images_per_sec": round(steps * B / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
+        same_counts = same_labels = score_diff = None
+        if ref_out is not None:
+            same_counts = bool(torch.equal(out["counts"], ref_out["counts"]))
+            same_labels = bool(torch.equal(out["cls"], ref_out["cls"]))
+            score_diff = float((out["score"] - ref_out["score"]).abs().max())
+        return {"images_per_sec": round(steps * B / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "body": body,
                 "convs_moved": moved, "dtype": "f32 results; the moved convs multiply bf16 pieces (3 per fp32 operand, 6 products per fp32 product) and accumulate in f32",
                 "same_detection_counts": same_counts, "same_labels_same_order": same_labels, "max_score_diff_vs_default": score_diff,
                 "status": "opt-in (CMK_ALLOW_SPLIT_BF16=1 + a variant table naming tune 10/32/4); not used by `value`"}
@@ -535,6 +537,8 @@ def main():
                 result["v99"] = other_body_leg("V-99-eSE", dev, B)
             if world == 1 and not args.no_extras:
                 result["split_gemm"] = split_gemm_leg(args.body, dev, B, out)
+                if args.body == "V-39-eSE":
+                    result["split_gemm_v99"] = split_gemm_leg("V-99-eSE", dev, B, None, steps=5, warmup=2)
             if cpu is not None:
                 result["cpu_baseline"] = cpu
                 result["ap_delta"] = ap
