@@ -63,5 +63,7 @@ int launch_wino6s(ConvArgs& a, int geo, hipStream_t st);
 int launch_pw(ConvArgs& a, int mt, hipStream_t st);
 // conv_pw.hip, opt-in: the same GEMM from bf16-split products (fp32-accurate; a.w = the split packing, cmk.h w_split)
 int launch_pw_split(ConvArgs& a, hipStream_t st);
+// conv_sp3.hip, opt-in: 3x3 stride-1 conv as a direct implicit GEMM on bf16-split products (halo tile in LDS, pieces 2 | 3, geo 0..3)
+int launch_sp3(ConvArgs& a, int geo, int pieces, hipStream_t st);
 
 }  // namespace cmk

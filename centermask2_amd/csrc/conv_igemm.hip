@@ -1012,6 +1012,22 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         a.ga_stride = d->ksize == 3 ? d->stride : 0;
         return launch_pw_split(a, st);
     }
+    if (d->tune_wm == 11) {                            // opt-in: direct 3x3 conv on bf16-split products (conv_sp3.hip); tune_sc = pieces, tune_wn = geometry
+        if (d->ksize != 3 || d->stride != 1 || !d->w_split || d->splitk > 1 || d->res_mode != 0 || d->in_relu || d->pool_ws)
+            return fail(CMK_EINVAL, "conv: the direct bf16-split variant needs w_split and a plain 3x3 stride-1 conv%s", "");
+        if (d->gn_ws) {
+            int rc = setup_gn(a, d);
+            if (rc) return rc;
+        }
+        for (int i = 0; i < n; ++i) {
+            if (!descs[i].w_split) return fail(CMK_EINVAL, "conv: w_split missing%s", "");
+            a.p[i].w = reinterpret_cast<const float*>(descs[i].w_split);
+        }
+        a.cout_pad = cdiv(cout32, 4) * 128;
+        a.w = reinterpret_cast<const float*>(d->w_split);
+        a.ksplit = 1;
+        return launch_sp3(a, d->tune_wn, d->tune_sc, st);
+    }
     if (d->tune_wm == 9) {                             // gather form of a 3x3 conv on the pointwise GEMM kernel; tune_wn = accumulator rows per wave
         const int mt = gather_mt(d, n);
         if (!mt) return fail(CMK_EINVAL, "conv: pointwise gather variant not available for this conv%s", "");
@@ -1113,8 +1129,14 @@ extern "C" int64_t cmk_conv_packed_floats(int Cout, int Cin, int ksize) {
 
 extern "C" int cmk_conv_gn_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 15) / 16); }
 
-// {sum, sumsq} records per image that a conv with fused GroupNorm statistics writes: tune_wm 5 -> 2 per 8x16 tile, 6 -> 4 per 12x40 tile
+// {sum, sumsq} records per image that a conv with fused GroupNorm statistics writes: tune_wm 5 -> 2 per 8x16 tile, 6 -> 4 per 12x40 tile,
+// 110 + g (tune_wm 11, geometry g: conv_sp3.hip) -> 2 per 8x32 (g 0) | 1 per 4x32 (1) | 2 per 16x16 (2) | 1 per 8x16 (3) tile
 extern "C" int cmk_conv_gn_records(int H, int W, int tune_wm) {
+    if (tune_wm >= 110 && tune_wm <= 113) {
+        const int g = tune_wm - 110;
+        const int th = g == 0 ? 8 : g == 1 ? 4 : g == 2 ? 16 : 8, tw = g < 2 ? 32 : 16;
+        return ((g & 1) ? 1 : 2) * ((H + th - 1) / th) * ((W + tw - 1) / tw);
+    }
     return tune_wm == 6 ? 4 * ((H + 11) / 12) * ((W + 39) / 40) : 2 * ((H + 7) / 8) * ((W + 15) / 16);
 }
 
@@ -1146,7 +1168,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         int rc = validate(&descs[i]);
         if (rc) return rc;
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
-        same_w = same_w && b->w == a->w && b->w_wino == a->w_wino && b->w_wino6 == a->w_wino6;
+        same_w = same_w && b->w == a->w && b->w_wino == a->w_wino && b->w_wino6 == a->w_wino6 && b->w_split == a->w_split;
         if (b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
             b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||
@@ -1155,7 +1177,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
     }
     // problems with different weights (the cls and the bbox tower of the FCOS head, fcos.py:227-231, in one launch) and more than 5 problems:
     // the F(4x4) kernels only, which take the packed weights per problem
-    if ((!same_w || n > 5) && (descs[0].tune_wm != 6 || descs[0].tune_wn != 1))
+    if ((!same_w || n > 5) && (descs[0].tune_wm != 6 || descs[0].tune_wn != 1) && descs[0].tune_wm != 11)
         return fail(CMK_EINVAL, "conv_multi: different weights per problem / more than 5 problems need tune_wm 6, tune_wn 1 (the F(4x4) map kernels)%s", "");
     for (int i = 0; i < n; ++i)
         if (descs[0].tune_wm == 6 && !descs[i].w_wino6) return fail(CMK_EINVAL, "conv_multi: w_wino6 missing%s", "");

@@ -208,10 +208,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
                 const f32x4 r1 = {x.x - f_lo(h.x), x.y - f_hi(h.x), x.z - f_lo(h.y), x.w - f_hi(h.y)};
                 m_.x = pk(r1.x, r1.y); m_.y = pk(r1.z, r1.w);
                 const f32x4 r2 = {r1.x - f_lo(m_.x), r1.y - f_hi(m_.x), r1.z - f_lo(m_.y), r1.w - f_hi(m_.y)};
-                l.x = pk(r2.x, r2.y); l.y = pk(r2.z, r2.w);
                 *reinterpret_cast<u32x2*>(dst + st_off[it]) = h;
                 *reinterpret_cast<u32x2*>(dst + st_off[it] + 64 * 16) = m_;
+#if !(PW_ABL & 16)
+                l.x = pk(r2.x, r2.y); l.y = pk(r2.z, r2.w);
                 *reinterpret_cast<u32x2*>(dst + st_off[it] + 2 * 64 * 16) = l;
+#endif
             }
         };
         const u32x4* wsp = reinterpret_cast<const u32x4*>(a.w) + ((long)(co0 >> 5) * 3) * 64 + lane;      // wave-uniform base + lane
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-                for (int p_ = 0; p_ < 3; ++p_) wb[nn][p_] = wsp[chunk * wstep + (nn * 3 + p_) * 64];
+                for (int p_ = 0; p_ < ((PW_ABL & 16) ? 2 : 3); ++p_) wb[nn][p_] = wsp[chunk * wstep + (nn * 3 + p_) * 64];
         };
         // (GA: load_A walks the 9 taps x Cin / 16 chunks in order, re-pointing the rows per tap; the split weights are packed tap-major to match)
         load_A(0);
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
             load_Bs(min(c + 1, nchunks - 1));
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const u32x4 ah = ap[(m * 3 + 0) * 64], am = ap[(m * 3 + 1) * 64], al = ap[(m * 3 + 2) * 64];
+                const u32x4 ah = ap[(m * 3 + 0) * 64], am = ap[(m * 3 + 1) * 64], al = (PW_ABL & 16) ? am : ap[(m * 3 + 2) * 64];
                 if (m == 1) {           // the next chunk's activations (in registers since the last chunk) are split between the MFMA groups
                     stage((c + 1) & 1);
                     load_A(min(c + 2, nchunks - 1));
@@ -249,9 +251,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
                 for (int nn = 0; nn < 2; ++nn) {
                     const bf16x8 Bh = __builtin_bit_cast(bf16x8, wc[nn][0]), Bm = __builtin_bit_cast(bf16x8, wc[nn][1]), Bl = __builtin_bit_cast(bf16x8, wc[nn][2]);
                     f32x16 cacc = acc[m][nn];
+#if !(PW_ABL & 16)
                     cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, cacc, 0, 0, 0);
                     cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, cacc, 0, 0, 0);
                     cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, cacc, 0, 0, 0);
+#endif
                     cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, cacc, 0, 0, 0);
                     cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, cacc, 0, 0, 0);
                     cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, cacc, 0, 0, 0);

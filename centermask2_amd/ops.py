@@ -183,8 +183,9 @@ class PackedConv:
         # F(4x4,3x3) weights: 4x the 3x3 filter bank; packed for every conv that can use them (PACK_WINO6 = False skips it)
         self.w_wino6 = pack_wino6_weight(weight).to(device) if (PACK_WINO6 and self.k == 3 and stride == 1 and self.cin >= 32) else None
         # opt-in (ALLOW_SPLIT_BF16): the bf16-split packing for the pointwise GEMM's fp32-accurate split form (cmk.h tune_wm 10)
-        self.w_split = pack_split_weight(weight).to(device) if (ALLOW_SPLIT_BF16 and self.cin_pad % 32 == 0 and (
-            (self.k == 1 and self.cout > 224) or (self.k == 3 and (self.cout > 224 or 96 < self.cout <= 128)))) else None
+        self.w_split = pack_split_weight(weight).to(device) if ((ALLOW_SPLIT_BF16 and self.cin_pad % 32 == 0 and (
+            (self.k == 1 and self.cout > 224) or (self.k == 3 and (self.cout > 224 or 96 < self.cout <= 128)))) or (
+            ALLOW_SPLIT_BF16X3 and self.k == 3 and stride == 1 and self.cin >= 32)) else None
         self.scale = (torch.ones(self.cout) if scale is None else scale.detach().float().cpu()).contiguous().to(device)
         self.shift = (torch.zeros(self.cout) if shift is None else shift.detach().float().cpu()).contiguous().to(device)
 
@@ -232,6 +233,9 @@ FUSE_POOL = os.environ.get("CMK_FUSE_POOL", "1") != "0"      # eSE: average-pool
 PAIR_TOWERS = os.environ.get("CMK_PAIR_TOWERS", "1") != "0"  # FCOS head: conv k of the cls and the bbox tower in one launch (A/B switch)
 ALLOW_SPLIT_BF16 = os.environ.get("CMK_ALLOW_SPLIT_BF16", "0") == "1"   # OPT-IN: pack the bf16-split weights and let the tuner / tables use the
                           # pointwise GEMM's split form (fp32-accurate products from bf16 pieces, cmk.h tune_wm 10).  Off: nothing in the package uses it.
+ALLOW_SPLIT_BF16X3 = os.environ.get("CMK_ALLOW_SPLIT_BF16X3", "0") == "1"   # OPT-IN, a second level: 3x3 stride-1 convs as a direct implicit GEMM on
+                          # TWO bf16 pieces per operand / three products (cmk.h tune_wm 11, tune_sc 2): a 16-bit significand — measured error below the
+                          # fp32 Winograd form's, but not fp32 products.  Off: nothing in the package uses it.
 PACK_WINO6 = True         # pack the F(4x4,3x3) weights too (4x the filter bank per 3x3 stride-1 conv)
 ALLOW_WINOGRAD = True     # let the tuner pick the Winograd F(2x2,3x3) kernel where it is faster (fp32, differs by rounding only)
 FORCE_VARIANT = None      # (wm, sc, wn[, splitk]) for every conv launched through the wrappers below (tests, A/B tools); None = table/tuner/default
@@ -276,6 +280,8 @@ def _variant_on_menu(tv) -> bool:
         return wn in (1, 2) and sk == 1
     if wm == 10:                      # pointwise GEMM from bf16-split products: only where the caller opted in
         return ALLOW_SPLIT_BF16 and sc == 32 and wn == 4 and sk == 1
+    if wm == 11:                      # direct 3x3 conv from bf16-split products (conv_sp3.hip): sc = pieces, wn = geometry
+        return ((sc == 3 and ALLOW_SPLIT_BF16) or (sc == 2 and ALLOW_SPLIT_BF16X3)) and 0 <= wn <= 3 and sk == 1
     return (wm in (1, 2, 5, 6, 7, 8, 9) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
 
 
@@ -336,6 +342,8 @@ def _tune(descs, n, key) -> None:
         cands += [(9, 32, mt, sk) for mt in (4, 2) for sk in sks]   # gather form of a 3x3 conv on the pointwise GEMM kernel (conv_pw.hip GA)
         if ALLOW_SPLIT_BF16:
             cands += [(10, 32, 4, 1)]                               # ... and its opt-in bf16-split form
+        if ALLOW_SPLIT_BF16X3:
+            cands += [(11, 2, g, 1) for g in range(4)]              # opt-in: direct 3x3 on two bf16 pieces per operand (conv_sp3.hip), four tile geometries
     if d0.ksize == 1:
         cands += [(8, 32, mt, sk) for mt in (4, 2) for sk in sks]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
         if ALLOW_SPLIT_BF16:
@@ -469,8 +477,8 @@ def conv_gn_multi(xs: Sequence[View], pcs: Sequence[PackedConv], gamma: torch.Te
     d0 = descs[0]
     cpg = pc.cout // groups if groups > 0 and pc.cout % groups == 0 else 0
     untuned = (d0.tune_wm, d0.tune_sc, d0.tune_wn) == (0, 0, 0)
-    wino = d0.tune_wm in (5, 6) or (untuned and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
-    gn_form = 6 if (d0.tune_wm == 6 or (untuned and _default_is_wino6(descs, n, pc))) else 5
+    wino = d0.tune_wm in (5, 6, 11) or (untuned and pc.w_wino is not None and pc.cin_pad >= 32 and pc.stride == 1)
+    gn_form = 110 + d0.tune_wn if d0.tune_wm == 11 else 6 if (d0.tune_wm == 6 or (untuned and _default_is_wino6(descs, n, pc))) else 5
     fused = wino and 0 < cpg <= 32 and (cpg & (cpg - 1)) == 0 and all(x.t.shape[0] == xs[0].t.shape[0] for x in xs)
     if not fused:
         launch()
@@ -527,11 +535,12 @@ def conv_gn_multi_pair(xs_a: Sequence[View], pc_a: PackedConv, gn_a, xs_b: Seque
     tv = FORCE_VARIANT if FORCE_VARIANT is not None else _TUNED.get(key)
     if tv is None:
         tv = (6, 16, 1) if _default_is_wino6(half, na, pc_a) else None
-    if tv is None or tv[0] != 6 or tv[2] != 1:
+    sp3 = tv is not None and tv[0] == 11 and pc_a.w_split is not None and pc_b.w_split is not None      # opt-in direct bf16-split form
+    if tv is None or not (sp3 or (tv[0] == 6 and tv[2] == 1)):
         return None
     _set_variant(descs, n, tv)
     nimg, dev = xs[0].t.shape[0], xs[0].t.device
-    recs_l = [lib.cmk_conv_gn_records(y.t.shape[1], y.t.shape[2], 6) for y in ys]
+    recs_l = [lib.cmk_conv_gn_records(y.t.shape[1], y.t.shape[2], 110 + tv[2] if sp3 else 6) for y in ys]
     gws = torch.empty((nimg * sum(recs_l), groups, 2), dtype=torch.float64, device=dev)
     for i in range(n):
         descs[i].gn_ws, descs[i].gn_groups = gws.data_ptr(), groups
@@ -884,7 +893,7 @@ def kernel_source_hash() -> str:
     import os
     h = hashlib.sha1()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-    for f in ("conv_args.hpp", "wino6_common.hpp", "conv_igemm.hip", "conv_wino6.hip", "conv_wino6s.hip", "conv_pw.hip"):
+    for f in ("conv_args.hpp", "wino6_common.hpp", "conv_igemm.hip", "conv_wino6.hip", "conv_wino6s.hip", "conv_pw.hip", "conv_sp3.hip"):
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:12]
 
@@ -930,6 +939,8 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False) -> str:
         return "conv_pw_kernel<{}, {}, false, {}, {}, false>".format(wn, "true" if pool else "false", "true" if upres else "false", sk)
     if wm == 10:
         return "conv_pw_kernel<4, {}, {}, {}, false, true>".format("true" if pool else "false", "true" if taps == 9 else "false", "true" if upres else "false")
+    if wm == 11:
+        return "conv_sp3_kernel<{}, 2, {}, {}>".format(wn, sc, "true" if aff else "false")
     if wm == 9:
         return "conv_pw_kernel<{}, false, true, false, {}, false>".format(wn, sk)
     if wm == 7:

@@ -751,3 +751,92 @@ def test_maxpool_with_folded_ese_gate(dev):
     y = ops.maxpool3x3s2_ceil(ops.as_view(x.to(dev)), gate=gate.to(dev))
     torch.cuda.synchronize()
     _close(y.nchw(), ref, 1e-6)
+
+
+SP3_CASES = [  # (n, h, w, cin, cout, geo, pieces): ragged maps, cout padding, every tile geometry; three pieces are refused
+    (2, 37, 53, 64, 128, 0, 2), (1, 21, 70, 48, 80, 1, 2), (3, 14, 14, 256, 256, 2, 2), (2, 50, 80, 128, 256, 3, 2), (2, 13, 20, 32, 33, 0, 2),
+    (1, 9, 33, 272, 160, 3, 2), (2, 8, 32, 64, 128, 0, 3), (1, 19, 45, 96, 224, 1, 2)]
+
+
+@pytest.mark.parametrize("case", SP3_CASES)
+def test_conv_direct_split_bf16_form(dev, case, monkeypatch):
+    """OPT-IN tune_wm 11 (conv_sp3.hip): 3x3 stride-1 conv as a direct implicit GEMM on bf16 pieces of the fp32 operands — two pieces /
+    three products (16-bit significand): within 1.5e-4 of a FLOAT64 conv on unit-variance outputs, the fp32 F(4x4) Winograd form's own
+    distance; output channel views, partial ReLU, every geometry; refused without the packing or with another piece count."""
+    import ctypes
+    from centermask2_amd import _lib
+    n, h, w, cin, cout, geo, pieces = case
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16", True)
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16X3", True)
+    x = _rand((n, cin, h, w), 401)
+    wt = _rand((cout, cin, 3, 3), 402, (1.0 / (9 * cin)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(403)) + 0.5
+    shift = _rand((cout,), 404, 0.1)
+    pc = ops.PackedConv(wt, scale, shift, dev)
+    assert pc.w_split is not None
+    relu_upto = cout // 2
+    ref = F.conv2d(x.double(), wt.double(), padding=1) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    ref[:, :relu_upto] = ref[:, :relu_upto].relu()
+    xv = ops.as_view(x.to(dev))
+    big = torch.full((n, h, w, cout + 24), float("nan"), device=dev)         # the output is a channel slice of a wider buffer (the OSA concat)
+    y = View(big, 16, cout)
+    d = (_lib.ConvDesc * 1)()
+    ops._fill_desc(d[0], xv, pc, y, False, relu_upto, None, False, False)
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 11, pieces, geo
+    lib = _lib.load()
+    if pieces != 2:
+        assert lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
+        return
+    _lib.check(lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "conv_sp3")
+    torch.cuda.synchronize()
+    got = big[..., 16:16 + cout].permute(0, 3, 1, 2).double().cpu()
+    assert bool(torch.isnan(big[..., :16]).all()) and bool(torch.isnan(big[..., 16 + cout:]).all())       # nothing written outside the view
+    err = float((got - ref).abs().max())
+    assert err <= 1.5e-4, err
+    d[0].w_split = None
+    assert lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0                                    # no packing: refused, not emulated
+
+
+@pytest.mark.parametrize("geo", [0, 1, 2, 3])
+@pytest.mark.parametrize("with_affine", [False, True])
+def test_conv_direct_split_tower_launches(dev, geo, with_affine, monkeypatch):
+    """The FCOS tower launches on the opt-in direct split form: five levels in one launch, the fused GroupNorm + ReLU of the previous layer
+    applied while staging (padding stays zero), the {sum, sumsq} records of the next GroupNorm from the epilogue, and two towers with
+    different weights as ONE launch — against float64 convolutions / statistics."""
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16X3", True)
+    monkeypatch.setattr(ops, "FORCE_VARIANT", (11, 2, geo))
+    g = torch.Generator().manual_seed(88)
+    shapes = [(2, 20, 36), (2, 9, 17), (2, 5, 3), (2, 3, 2), (2, 1, 1)]
+    cin = cout = 64
+    groups = 32
+    ws_ = [torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5 for _ in range(2)]
+    bs_ = [torch.randn((cout,), generator=g) * 0.1 for _ in range(2)]
+    pcs = [ops.PackedConv(w_, None, b_, dev) for w_, b_ in zip(ws_, bs_)]
+    gn = [((torch.rand((cout,), generator=g) + 0.5).to(dev), (torch.randn((cout,), generator=g) * 0.1).to(dev)) for _ in range(2)]
+    xs_cpu = [torch.randn((n, cin, h, w), generator=g) for n, h, w in shapes]
+    xs = [ops.as_view(x.to(dev)) for x in xs_cpu]
+    affs = [None, None]
+    if with_affine:
+        affs = [[((torch.rand((n, cin), generator=g) + 0.5).to(dev), (torch.randn((n, cin), generator=g) * 0.2).to(dev)) for n, _, _ in shapes] for _ in range(2)]
+    pair = ops.conv_gn_multi_pair(xs, pcs[0], gn[0], xs, pcs[1], gn[1], groups, 1e-5, in_affine_a=affs[0], in_affine_b=affs[1])
+    assert pair is not None
+    single = ops.conv_gn_multi(xs, [pcs[0]] * 5, gn[0][0], gn[0][1], groups, 1e-5, in_affine=affs[0])
+    torch.cuda.synchronize()
+    for t, (ys, aff) in enumerate(pair):
+        for l, (x, y, (sc, sh)) in enumerate(zip(xs_cpu, ys, aff)):
+            xin = x.double()
+            if with_affine:
+                a_sc, a_sh = affs[t][l]
+                xin = (xin * a_sc.cpu().double()[:, :, None, None] + a_sh.cpu().double()[:, :, None, None]).relu()
+            ref = F.conv2d(xin, ws_[t].double(), bs_[t].double(), padding=1)
+            assert float((y.nchw().double().cpu() - ref).abs().max()) <= 3e-4
+            n, c = ref.shape[:2]
+            r = ref.reshape(n, groups, -1)
+            mean, var = r.mean(2), r.var(2, unbiased=False)
+            rstd = (1.0 / torch.sqrt(var + 1e-5)).repeat_interleave(c // groups, 1)
+            ref_sc = rstd * gn[t][0].cpu().double()[None]
+            ref_sh = gn[t][1].cpu().double()[None] - mean.repeat_interleave(c // groups, 1) * ref_sc
+            assert float((sc.cpu().double() - ref_sc).abs().max()) <= 2e-3 * float(ref_sc.abs().max())
+            assert float((sh.cpu().double() - ref_sh).abs().max()) <= 2e-3 * max(1.0, float(ref_sh.abs().max()))
+    for y, yr, (sc_, sh_), (scr, shr) in zip(pair[0][0], single[0], pair[0][1], single[1]):      # the pair launch = the single launch, bit for bit
+        assert torch.equal(y.t, yr.t) and torch.equal(sc_, scr) and torch.equal(sh_, shr)

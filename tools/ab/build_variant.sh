@@ -8,7 +8,7 @@ NAME=$1; SRC=$(readlink -f "$2"); shift 2
 cd "$ROOT/centermask2_amd/csrc"
 mkdir -p ../ab build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -c -x hip "$SRC" -o build/w6_$NAME.o "$@"
-case "$(basename "$SRC")" in conv_pw*) REPL=conv_pw.o;; conv_wino6s*) REPL=conv_wino6s.o;; *) REPL=conv_wino6.o;; esac
+case "$(basename "$SRC")" in conv_pw*) REPL=conv_pw.o;; conv_wino6s*) REPL=conv_wino6s.o;; conv_sp3*) REPL=conv_sp3.o;; *) REPL=conv_wino6.o;; esac
 OBJS=$(ls build/*.o | grep -v "build/w6_" | grep -v $REPL)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../ab/libcmk_$NAME.so $OBJS build/w6_$NAME.o
 echo "built centermask2_amd/ab/libcmk_$NAME.so"
