@@ -282,19 +282,24 @@ def other_body_leg(body, dev, B, steps=5, warmup=2):
         ops._TUNED.update(saved)
 
 
-def split_gemm_leg(body, dev, B, ref_out=None, steps=20, warmup=3):
+def split_gemm_leg(body, dev, B, ref_out=None, steps=20, warmup=3, level=1):
     """OPT-IN path, reported beside `value`, never as it: the same step with the convs the pointwise GEMM kernel runs (OSA aggregation convs, FPN
     laterals, the mask head's deconv, stem_3 in the gather form) on its bf16-split form (cmk.h tune_wm 10: every fp32 product rebuilt from three bf16 pieces per operand, six MFMA
     products, fp32 accumulation — the error of an fp32 accumulation).  The detections are compared with the default
-    path's (`ref_out`): same counts, same labels in the same order, scores within 1e-4."""
+    path's (`ref_out`): same counts, same labels in the same order, scores within 1e-4.
+    level 2 (key `split_direct3x3`): additionally the 3x3 convs the measured table `tuned/..._split3.json` names run as direct implicit GEMMs on TWO
+    fp16 pieces per fp32 operand (cmk.h tune_wm 11, conv_sp3.hip: 22-bit operands, three products, fp32 accumulation: an fp32 accumulation's error)."""
     from centermask2_amd import ops, synthetic as S
-    saved, saved_flag = dict(ops._TUNED), ops.ALLOW_SPLIT_BF16
+    saved, saved_flag, saved_flag3 = dict(ops._TUNED), ops.ALLOW_SPLIT_BF16, ops.ALLOW_SPLIT_F16
     try:
         ops.ALLOW_SPLIT_BF16 = True
+        ops.ALLOW_SPLIT_F16 = level >= 2
         ops._TUNED.clear()
-        table = os.path.join(ROOT, "centermask2_amd", "tuned", "mi355x_{}_b{}_800x1280.json".format(body, B))
+        table = os.path.join(ROOT, "centermask2_amd", "tuned", "mi355x_{}_b{}_800x1280{}.json".format(body, B, "_split3" if level >= 2 else ""))
         if os.path.exists(table):
             ops.load_tuned(table)
+        elif level >= 2:
+            return {"status": "no measured table for this body"}
         moved = 0
         for k, v in list(ops._TUNED.items()):
             # every conv the pointwise GEMM kernel runs without split-K: plain 1x1 (8), 1x1 with the FPN top-down add (8, res 2), 3x3 in the gather form (9)
@@ -329,12 +334,20 @@ def split_gemm_leg(body, dev, B, ref_out=None, steps=20, warmup=3):
             same_counts = bool(torch.equal(out["counts"], ref_out["counts"]))
             same_labels = bool(torch.equal(out["cls"], ref_out["cls"]))
             score_diff = float((out["score"] - ref_out["score"]).abs().max())
-        return {"images_per_sec": round(steps * B / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "body": body,
-                "convs_moved": moved, "dtype": "f32 results; the moved convs multiply bf16 pieces (3 per fp32 operand, 6 products per fp32 product) and accumulate in f32",
-                "same_detection_counts": same_counts, "same_labels_same_order": same_labels, "max_score_diff_vs_default": score_diff,
-                "status": "opt-in (CMK_ALLOW_SPLIT_BF16=1 + a variant table naming tune 10/32/4); not used by `value`"}
+        moved = sum(1 for v in ops._TUNED.values() if v[0] == 10)
+        res = {"images_per_sec": round(steps * B / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "body": body,
+               "convs_moved": moved, "dtype": "f32 results; the moved convs multiply bf16 pieces (3 per fp32 operand, 6 products per fp32 product) and accumulate in f32",
+               "same_detection_counts": same_counts, "same_labels_same_order": same_labels, "max_score_diff_vs_default": score_diff,
+               "status": "opt-in (CMK_ALLOW_SPLIT_BF16=1 + a variant table naming tune 10/32/4); not used by `value`"}
+        if level >= 2:
+            res["convs_3x3_moved"] = sum(1 for v in ops._TUNED.values() if v[0] == 11)
+            res["dtype"] = ("f32 results; the 3x3 convs named by the table multiply 2 fp16 pieces per fp32 operand (22-bit operands, 3 products), the pointwise "
+                            "convs 3 bf16 pieces (6 products); f32 accumulation")
+            res["status"] = "opt-in, second level (CMK_ALLOW_SPLIT_F16=1 + tuned/*_split3.json); not used by `value`"
+        return res
     finally:
         ops.ALLOW_SPLIT_BF16 = saved_flag
+        ops.ALLOW_SPLIT_F16 = saved_flag3
         ops._TUNED.clear()
         ops._TUNED.update(saved)
 
@@ -537,6 +550,7 @@ def main():
                 result["v99"] = other_body_leg("V-99-eSE", dev, B)
             if world == 1 and not args.no_extras:
                 result["split_gemm"] = split_gemm_leg(args.body, dev, B, out)
+                result["split_direct3x3"] = split_gemm_leg(args.body, dev, B, out, level=2)
                 if args.body == "V-39-eSE":
                     result["split_gemm_v99"] = split_gemm_leg("V-99-eSE", dev, B, None, steps=5, warmup=2)
             if cpu is not None:

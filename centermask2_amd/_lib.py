@@ -30,6 +30,7 @@ class ConvDesc(Structure):
         ("w_wino6", c_void_p),
         ("pool_ws", c_void_p),
         ("w_split", c_void_p),
+        ("w_splith", c_void_p), ("w_splith_scale", c_float),
     ]
 
 
@@ -51,6 +52,7 @@ SIGNATURES = {
     "cmk_wino_packed_floats": (c_int64, [c_int, c_int]),
     "cmk_wino6_packed_floats": (c_int64, [c_int, c_int]),
     "cmk_split_packed_halves": (c_int64, [c_int, c_int]),
+    "cmk_splith_packed_halves": (c_int64, [c_int, c_int]),
     "cmk_conv_gn_records": (c_int, [c_int, c_int, c_int]),
     "cmk_dwconv3x3_nhwc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cmk_stem_conv_nchw3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

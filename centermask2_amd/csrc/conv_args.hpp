@@ -17,7 +17,8 @@ __host__ __device__ constexpr int occ_of(int wm, int wn, int stride) { return (s
 struct ConvProblem {
     const float* x; float* y; const float* scale; const float* shift;
     const float* in_scale; const float* in_shift;   // optional (N, Cin): x' = relu(x * in_scale + in_shift) while staging (fused GroupNorm+ReLU)
-    const float* w;                                 // F(4x4) kernels: this problem's packed U (problems of one launch may differ in weights); else unused
+    const float* w;                                 // F(4x4) kernels: this problem's packed U (problems of one launch may differ in weights); conv_sp3: its fp16 split packing
+    float acc_scale;                                // conv_sp3: 1 / S_w of this problem's weights (cmk.h w_splith_scale)
     int N, H, W, Ho, Wo;
     int tiles_h, tiles_w, tile_begin;
     long total_pix;  // N*Ho*Wo
@@ -63,7 +64,7 @@ int launch_wino6s(ConvArgs& a, int geo, hipStream_t st);
 int launch_pw(ConvArgs& a, int mt, hipStream_t st);
 // conv_pw.hip, opt-in: the same GEMM from bf16-split products (fp32-accurate; a.w = the split packing, cmk.h w_split)
 int launch_pw_split(ConvArgs& a, hipStream_t st);
-// conv_sp3.hip, opt-in: 3x3 stride-1 conv as a direct implicit GEMM on bf16-split products (halo tile in LDS, pieces 2 | 3, geo 0..3)
+// conv_sp3.hip, opt-in: 3x3 stride-1 conv as a direct implicit GEMM on fp16-split products (halo tile in LDS, 2 pieces per operand, geo 0..3)
 int launch_sp3(ConvArgs& a, int geo, int pieces, hipStream_t st);
 
 }  // namespace cmk

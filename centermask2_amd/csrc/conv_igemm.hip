@@ -1013,18 +1013,18 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         return launch_pw_split(a, st);
     }
     if (d->tune_wm == 11) {                            // opt-in: direct 3x3 conv on bf16-split products (conv_sp3.hip); tune_sc = pieces, tune_wn = geometry
-        if (d->ksize != 3 || d->stride != 1 || !d->w_split || d->splitk > 1 || d->res_mode != 0 || d->in_relu || d->pool_ws)
-            return fail(CMK_EINVAL, "conv: the direct bf16-split variant needs w_split and a plain 3x3 stride-1 conv%s", "");
+        if (d->ksize != 3 || d->stride != 1 || !d->w_splith || d->splitk > 1 || d->res_mode != 0 || d->in_relu || d->pool_ws)
+            return fail(CMK_EINVAL, "conv: the direct fp16-split variant needs w_splith and a plain 3x3 stride-1 conv%s", "");
         if (d->gn_ws) {
             int rc = setup_gn(a, d);
             if (rc) return rc;
         }
         for (int i = 0; i < n; ++i) {
-            if (!descs[i].w_split) return fail(CMK_EINVAL, "conv: w_split missing%s", "");
-            a.p[i].w = reinterpret_cast<const float*>(descs[i].w_split);
+            if (!descs[i].w_splith || !(descs[i].w_splith_scale > 0.f)) return fail(CMK_EINVAL, "conv: w_splith / w_splith_scale missing%s", "");
+            a.p[i].w = reinterpret_cast<const float*>(descs[i].w_splith);
+            a.p[i].acc_scale = descs[i].w_splith_scale;
         }
         a.cout_pad = cdiv(cout32, 4) * 128;
-        a.w = reinterpret_cast<const float*>(d->w_split);
         a.ksplit = 1;
         return launch_sp3(a, d->tune_wn, d->tune_sc, st);
     }
@@ -1140,6 +1140,10 @@ extern "C" int cmk_conv_gn_records(int H, int W, int tune_wm) {
     return tune_wm == 6 ? 4 * ((H + 11) / 12) * ((W + 39) / 40) : 2 * ((H + 7) / 8) * ((W + 15) / 16);
 }
 
+extern "C" int64_t cmk_splith_packed_halves(int Cout, int Cin) {     // per tap: two fp16 pieces per weight (cmk.h w_splith)
+    return (int64_t)((Cin + 15) / 16) * (((Cout + 127) / 128) * 4) * 2 * 64 * 8;
+}
+
 extern "C" int64_t cmk_split_packed_halves(int Cout, int Cin) {      // per tap of the conv: a 3x3 conv in the gather form holds nine of these, tap-major
     return (int64_t)((Cin + 15) / 16) * (((Cout + 127) / 128) * 4) * 3 * 64 * 8;
 }
@@ -1168,7 +1172,7 @@ extern "C" int cmk_conv2d_nhwc_multi(const cmk_conv_desc* descs, int n, void* st
         int rc = validate(&descs[i]);
         if (rc) return rc;
         const cmk_conv_desc *a = &descs[0], *b = &descs[i];
-        same_w = same_w && b->w == a->w && b->w_wino == a->w_wino && b->w_wino6 == a->w_wino6 && b->w_split == a->w_split;
+        same_w = same_w && b->w == a->w && b->w_wino == a->w_wino && b->w_wino6 == a->w_wino6 && b->w_split == a->w_split && b->w_splith == a->w_splith;
         if (b->Cin != a->Cin || b->Cout != a->Cout || b->ksize != a->ksize || b->stride != a->stride ||
             b->relu_upto != a->relu_upto || b->in_relu != a->in_relu || b->x_cs != a->x_cs || b->x_co != a->x_co || b->y_cs != a->y_cs ||
             b->y_co != a->y_co || b->res_mode != 0 || b->tune_wm != a->tune_wm || b->tune_sc != a->tune_sc || b->tune_wn != a->tune_wn || (b->in_scale == nullptr) != (a->in_scale == nullptr) ||

@@ -1,19 +1,28 @@
-// OPT-IN (cmk.h tune_wm 11): 3x3 stride-1 convolution as a DIRECT implicit GEMM on bf16-split products, v_mfma_f32_32x32x16_bf16.
+// OPT-IN (cmk.h tune_wm 11): 3x3 stride-1 convolution as a DIRECT implicit GEMM on fp16-split products, v_mfma_f32_32x32x16_f16.
 //
 // Why: the fp32 matrix instruction (157 TFLOP/s) holds the F(4x4,3x3) Winograd kernels at 75-90 executed = 300-360 direct-equivalent
-// TFLOP/s, for structural reasons.  The bf16 instruction runs at 2010.  Every fp32 operand is split into P bf16 pieces
-// (P = 2: x = hi + mid, round to nearest even) and the products of weight >= 2^-8 — mid*hi, hi*mid, hi*hi: a 16-bit significand, measured max
-// error 3e-5..5e-5 on unit-variance outputs, BELOW the fp32 Winograd form's 7e-5..1.6e-4 (tools/bench_sp3.py) — are accumulated in fp32, small
-// terms first.  No transform, so no Winograd error amplification either.  (Three pieces / six products, the error of an fp32 fma chain, run
-// slower than Winograd on a 3x3 conv; that form is the gather variant of conv_pw.hip, tune_wm 10.)
+// TFLOP/s, for structural reasons.  The 16-bit instructions run at 2010.  Every fp32 operand is split into TWO fp16
+// pieces — x = h + m, h = fp16(x), m = fp16(x - h): 11 + 11 = 22 bits of significand, the residual x - h is exact in fp32 — and the three
+// products m*h, h*m, h*h are accumulated in fp32, small terms first (what is dropped, m*m, is 2^-22 of the product).  Measured: the
+// representation error is a third of an fp32 GEMM's own accumulation error (tools/split_bf16_numerics.py), i.e. the result carries the error
+// of an fp32 accumulation.  (Two BF16 pieces, 16 bits, were built first and measured 5x the fp32 path's end-to-end error: reg 1.4e-3 against
+// the 1e-3 bar; three bf16 pieces / six products are fp32-accurate but slower than Winograd on a 3x3 conv — profiles/r03_ablations.txt.)
+// fp16's narrow exponent is handled by scaling, all powers of two (exact):
+//   activations  x' = x * 2^-4 (|x| up to 1e6 stays finite); the residual is stored as fp16((x' - h) * 2^11), so it keeps 11 bits down to
+//                |x| = 2^-21 (unscaled it would be subnormal below |x| = 0.06), and the weight piece it meets is multiplied by 2^-11 in
+//                registers (4 packed multiplies per tap and cout tile);
+//   weights      w' = w * S_w with S_w the power of two that puts max |w'| in [2^14, 2^15) (host, per conv): both pieces of every weight
+//                larger than 2^-17 of the largest are normal fp16;
+//   the accumulator is multiplied by 2^4 / S_w in the epilogue (folded into the per-channel scale).
+// No transform, so no Winograd error amplification either.
 //
 // What the gather form of conv_pw.hip (tune_wm 10 on a 3x3 conv) pays nine times — the activation load, the split, the LDS write — is
 // paid once here: a workgroup stages the HALO of its pixel tile, 16 input channels at a time, split into pieces, as
-//   LDS [stage 2][piece P][k half 2][halo row][pitch][8 bf16]
+//   LDS [stage 2][piece P][k half 2][halo row][pitch][8 fp16]
 // and the nine taps read the MFMA's A operand (32 pixels = a 4 x 8 patch, lane (li, hh) = pixel li, channels 8hh..8hh+7 of the chunk)
 // from it at a shifted address (an immediate offset of the ds_read).  The row pitch (40 | 24 sixteen-byte units) makes the four rows of a
 // patch tile the 512-byte bank space.  The weights come straight from L2/L1 into registers through a wave-uniform base, one tap ahead
-// (cmk_conv_desc.w_split: [tap][Cin/16][cout_pad/32][piece 3][lane][8 bf16], the packing of the gather form; P = 2 skips the third piece).
+// (cmk_conv_desc.w_splith: [tap][Cin/16][cout_pad/32][piece 2][lane][8 fp16]).
 //
 // Workgroup = 4 waves, wave tile = 4 patches (128 pixels) x NB cout tiles of 32, accumulators as in conv_pw (pixels on the rows, couts on the lanes):
 //   GEO 0: waves 2 (pixels) x 2 (couts);  tile  8 rows x 32 columns x 128 couts      the large maps of 128-cout layers (200 x 320)
@@ -65,7 +74,6 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
     typedef SP3L<GEO, P> L;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     constexpr int WROWS = 4 / G::WCOLS;
     constexpr int IT = L::IT;
     extern __shared__ __attribute__((aligned(16))) unsigned char sb[];
@@ -127,16 +135,19 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < IT; ++it) load_X1(chunk, it);
     };
-    auto pk = [](float x, float y) { unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-    auto f_lo = [](unsigned p_) { return __builtin_bit_cast(float, p_ << 16); };
-    auto f_hi = [](unsigned p_) { return __builtin_bit_cast(float, p_ & 0xffff0000u); };
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr float SX = 0.0625f, RS = 2048.f;       // activation scale 2^-4, residual scale 2^11
+    auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, f16x2{(_Float16)x, (_Float16)y}); };       // round to nearest even
+    auto unpk = [](unsigned p_) { const f16x2 h_ = __builtin_bit_cast(f16x2, p_); return f32x2{(float)h_.x, (float)h_.y}; };
     auto stage = [&](int buf, int chunk) {
 #if !(SP3_ABL & 2)
         unsigned char* dst = sb + buf * L::STAGE;
-        f32x4 isc = {1.f, 1.f, 1.f, 1.f}, ish = {0.f, 0.f, 0.f, 0.f};
+        f32x4 isc = {SX, SX, SX, SX}, ish = {0.f, 0.f, 0.f, 0.f};
         if constexpr (AFF) {
-            isc = *reinterpret_cast<const f32x4*>(Pb.in_scale + (long)n * a.Cin + chunk * 16 + q * 4);
-            ish = *reinterpret_cast<const f32x4*>(Pb.in_shift + (long)n * a.Cin + chunk * 16 + q * 4);
+            isc = *reinterpret_cast<const f32x4*>(Pb.in_scale + (long)n * a.Cin + chunk * 16 + q * 4) * SX;
+            ish = *reinterpret_cast<const f32x4*>(Pb.in_shift + (long)n * a.Cin + chunk * 16 + q * 4) * SX;
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
@@ -147,10 +158,13 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
                 x.y = in ? fmaxf(fmaf(x.y, isc.y, ish.y), 0.f) : 0.f;
                 x.z = in ? fmaxf(fmaf(x.z, isc.z, ish.z), 0.f) : 0.f;
                 x.w = in ? fmaxf(fmaf(x.w, isc.w, ish.w), 0.f) : 0.f;
+            } else {
+                x *= SX;
             }
             u32x2 h, m_;
             h.x = pk(x.x, x.y); h.y = pk(x.z, x.w);
-            const f32x4 r1 = {x.x - f_lo(h.x), x.y - f_hi(h.x), x.z - f_lo(h.y), x.w - f_hi(h.y)};
+            const f32x2 h01 = unpk(h.x), h23 = unpk(h.y);
+            const f32x4 r1 = f32x4{x.x - h01.x, x.y - h01.y, x.z - h23.x, x.w - h23.y} * RS;      // exact: h holds the leading bits of x
             m_.x = pk(r1.x, r1.y); m_.y = pk(r1.z, r1.w);
             if (it < IT - 1 || st_dst[it] >= 0) {
                 *reinterpret_cast<u32x2*>(dst + st_dst[it]) = h;
@@ -161,11 +175,11 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
     };
 
     // ---- weights: wave-uniform base + lane ----------------------------------------------------------------------------------------------------
-    const u32x4* wsp = reinterpret_cast<const u32x4*>(Pb.w ? Pb.w : a.w) + lane;      // (problems of one launch may differ in weights: the two FCOS towers)
+    const u32x4* wsp = reinterpret_cast<const u32x4*>(Pb.w) + lane;      // (problems of one launch may differ in weights: the two FCOS towers)
     int wblk[NB];
 #pragma unroll
-    for (int nn = 0; nn < NB; ++nn) wblk[nn] = ((SP3_ABL & 64) ? nn : min(cb0 + nn, nblocks - 1)) * 3 * 64;       // (tiles past cout_pad: any valid block, never stored)
-    static_assert(P == 2, "two pieces per operand: the six-product form (three pieces) of a 3x3 conv is the gather form of conv_pw.hip, tune_wm 10");
+    for (int nn = 0; nn < NB; ++nn) wblk[nn] = ((SP3_ABL & 64) ? nn : min(cb0 + nn, nblocks - 1)) * P * 64;       // (tiles past cout_pad: any valid block, never stored)
+    static_assert(P == 2, "two fp16 pieces per operand");
     constexpr int BD = 2;                   // taps a weight request runs ahead (BD + 1 register sets; 9 taps % (BD + 1) == 0: no set is indexed at run time)
     constexpr int ST = 3, XT = 4;           // the tap after whose MFMAs the next chunk's halo is split and written / at which the one after is requested
     u32x4 wq[BD + 1][NB][P];
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
 #if SP3_ABL & 64
         const long k = 0 * (tap + chunk);        // every request of the launch hits the same lines
 #else
-        const long k = ((long)tap * nchunks + chunk) * nblocks * 3 * 64;
+        const long k = ((long)tap * nchunks + chunk) * nblocks * P * 64;
 #endif
 #pragma unroll
         for (int j = 0; j < NB * P; ++j)
@@ -226,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int set = tap % (BD + 1);
+            f16x8 Bhs[NB];              // the main weight piece x 2^-11: meets the activations' scaled residual
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 // the requests are spread over the patches: four in a row find the texture unit's queue full and hold the wave's MFMAs back
@@ -243,15 +258,19 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
                 if (m < 3) read_A((m + 1) & 1, tap, m + 1);
                 else if (tap < 8) read_A((m + 1) & 1, tap + 1, 0);
                 __builtin_amdgcn_sched_barrier(0);        // (the compiler otherwise sinks the requests to just before their use: no run-ahead left)
-                const bf16x8 Ah = __builtin_bit_cast(bf16x8, av[m & 1][0]), Am = __builtin_bit_cast(bf16x8, av[m & 1][1]);
+                const f16x8 Ah = __builtin_bit_cast(f16x8, av[m & 1][0]), Am = __builtin_bit_cast(f16x8, av[m & 1][1]);
 #if !(SP3_ABL & 16)
+                if (m == 0) {
+#pragma unroll
+                    for (int nn = 0; nn < NB; ++nn) Bhs[nn] = __builtin_bit_cast(f16x8, wq[set][nn][0]) * (_Float16)(1.f / RS);
+                }
 #pragma unroll
                 for (int nn = 0; nn < NB; ++nn) {
-                    const bf16x8 Bh = __builtin_bit_cast(bf16x8, wq[set][nn][0]), Bm = __builtin_bit_cast(bf16x8, wq[set][nn][1]);
+                    const f16x8 Bh = __builtin_bit_cast(f16x8, wq[set][nn][0]), Bm = __builtin_bit_cast(f16x8, wq[set][nn][1]);
                     f32x16 cacc = acc[m][nn];
-                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, cacc, 0, 0, 0);
-                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, cacc, 0, 0, 0);
-                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Am, Bhs[nn], cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bm, cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, cacc, 0, 0, 0);
                     acc[m][nn] = cacc;
                 }
 #endif
@@ -272,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
     // fused GroupNorm statistics of the NEXT layer's normalisation (fcos.py:182-186): one {sum, sumsq} record per (spatial tile, pixel row of
     // waves), every group of it written by the wave that owns those couts (cmk_conv_gn_records: WROWS records per tile)
     const bool want_stats = a.gn_ws != nullptr;
+    const float acc_scale = Pb.acc_scale * (1.f / SX);          // 1 / (S_x * S_w)
     auto put_stats = [&](int co, bool cvalid, float gs, float gss) {
         for (int o = 1; o < a.gn_cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
         gs += __shfl_xor(gs, 32);
@@ -293,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
 #pragma unroll
         for (int nn = 0; nn < NB; ++nn) {
             const int co = (cb0 + nn) * 32 + li;
-            float sc = Pb.scale[co], sh = Pb.shift[co];
+            float sc = Pb.scale[co] * acc_scale, sh = Pb.shift[co];
             const float lo = co < a.relu_upto ? 0.f : __builtin_nanf("");      // max(v, NaN) = v: lanes without the ReLU
             asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(sc), "+v"(sh));     // waited for once, here
             const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
         for (int nn = 0; nn < NB; ++nn) {
             const int co = (cb0 + nn) * 32 + li;
             const bool cvalid = co < a.Cout;
-            float sc = cvalid ? Pb.scale[co] : 0.f, sh = cvalid ? Pb.shift[co] : 0.f;
+            float sc = cvalid ? Pb.scale[co] * acc_scale : 0.f, sh = cvalid ? Pb.shift[co] : 0.f;
             const float lo = co < a.relu_upto ? 0.f : __builtin_nanf("");
             asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(sc), "+v"(sh));
             const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
@@ -407,14 +427,14 @@ static int launch_sp3_geo(ConvArgs& a, hipStream_t st) {
     return check_launch("conv_sp3");
 }
 
-// geo 0..3 (above), pieces = 2.  a.w = the split packing (tap-major), a.cout_pad = its padded Cout (a multiple of 128).
+// geo 0..3 (above), pieces = 2.  p[i].w = the fp16 split packing (tap-major), p[i].acc_scale = 1 / S_w, a.cout_pad = the packing's padded Cout (a multiple of 128).
 int launch_sp3(ConvArgs& a, int geo, int pieces, hipStream_t st) {
     if ((a.Cin & 15) || a.cout_pad % 128 || a.cout_pad < a.Cout || a.ksplit > 1 || a.res_mode != 0 || a.in_relu)
         return fail(CMK_EINVAL, "conv_sp3: needs Cin %% 16 == 0, no split-K / residual%s", "");
     for (int i = 0; i < a.nprob; ++i) {
         const ConvProblem& p = a.p[i];
-        if ((long)p.N * p.H * p.W * a.x_cs * 4 >= (1L << 31) || p.Ho != p.H || p.Wo != p.W || (!p.in_scale) != (!a.p[0].in_scale))
-            return fail(CMK_EINVAL, "conv_sp3: an input of 2 GiB or more, a strided conv, or problems that differ in the input affine%s", "");
+        if ((long)p.N * p.H * p.W * a.x_cs * 4 >= (1L << 31) || p.Ho != p.H || p.Wo != p.W || (!p.in_scale) != (!a.p[0].in_scale) || !p.w || !(p.acc_scale > 0.f))
+            return fail(CMK_EINVAL, "conv_sp3: an input of 2 GiB or more, a strided conv, problems that differ in the input affine, or no split weights%s", "");
     }
     if (pieces != 2) return fail(CMK_EINVAL, "conv_sp3: tune_sc = pieces per operand must be 2 (three pieces: tune_wm 10, the gather form of conv_pw)%s", "");
     switch (geo) {

@@ -168,6 +168,29 @@ def pack_split_weight(w: torch.Tensor) -> torch.Tensor:
     return r.reshape(cin_pad // 16, cout_pad // 32, 3, 64, 8)
 
 
+def pack_splith_weight(w: torch.Tensor):
+    """(Cout, Cin, 3, 3) fp32 -> (the fp16 two-piece packing of cmk_conv_desc.w_splith, 1 / S_w) for the opt-in direct form (tune_wm 11):
+    w' = w * S_w with S_w the power of two that puts max |w'| in [2^14, 2^15); pieces h = fp16(w'), m = fp16(w' - h) (the residual is exact in
+    fp32); laid out [tap][Cin/16][cout_pad/32][piece][lane = 32*hh + li][8]: input channel 16*chunk + 8*hh + e of output channel 32*tile + li;
+    cout_pad = Cout rounded up to 128, zero filled."""
+    import math
+    lib = _lib.load()
+    cout, cin = w.shape[0], w.shape[1]
+    cin_pad, cout_pad = (cin + 15) // 16 * 16, (cout + 127) // 128 * 128
+    wf = w.detach().float().cpu()
+    amax = float(wf.abs().max())
+    s_w = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+    full = torch.zeros((cout_pad, 9, cin_pad), dtype=torch.float32)
+    full[:cout, :, :cin] = wf.permute(0, 2, 3, 1).reshape(cout, 9, cin) * s_w
+    h = full.to(torch.float16)
+    m = (full - h.float()).to(torch.float16)
+    st = torch.stack([h, m], 0)                                                     # (2, cout_pad, 9, cin_pad)
+    r = st.reshape(2, cout_pad // 32, 32, 9, cin_pad // 16, 2, 8)                   # [piece][tile][li][tap][chunk][hh][e]
+    r = r.permute(3, 4, 1, 0, 5, 2, 6).contiguous()                                 # [tap][chunk][tile][piece][hh][li][e]
+    assert r.numel() == 9 * lib.cmk_splith_packed_halves(cout, cin_pad)
+    return r.reshape(9, cin_pad // 16, cout_pad // 32, 2, 64, 8), 1.0 / s_w
+
+
 class PackedConv:
     """Device-resident packed weights + per-channel epilogue (scale, shift) of one conv / linear layer."""
 
@@ -183,9 +206,13 @@ class PackedConv:
         # F(4x4,3x3) weights: 4x the 3x3 filter bank; packed for every conv that can use them (PACK_WINO6 = False skips it)
         self.w_wino6 = pack_wino6_weight(weight).to(device) if (PACK_WINO6 and self.k == 3 and stride == 1 and self.cin >= 32) else None
         # opt-in (ALLOW_SPLIT_BF16): the bf16-split packing for the pointwise GEMM's fp32-accurate split form (cmk.h tune_wm 10)
-        self.w_split = pack_split_weight(weight).to(device) if ((ALLOW_SPLIT_BF16 and self.cin_pad % 32 == 0 and (
-            (self.k == 1 and self.cout > 224) or (self.k == 3 and (self.cout > 224 or 96 < self.cout <= 128)))) or (
-            ALLOW_SPLIT_BF16X3 and self.k == 3 and stride == 1 and self.cin >= 32)) else None
+        self.w_split = pack_split_weight(weight).to(device) if (ALLOW_SPLIT_BF16 and self.cin_pad % 32 == 0 and (
+            (self.k == 1 and self.cout > 224) or (self.k == 3 and (self.cout > 224 or 96 < self.cout <= 128)))) else None
+        # opt-in (ALLOW_SPLIT_F16): the fp16 two-piece packing for the direct 3x3 form (cmk.h tune_wm 11)
+        self.w_splith, self.w_splith_scale = None, 0.0
+        if ALLOW_SPLIT_F16 and self.k == 3 and stride == 1 and self.cin >= 32:
+            wh_, self.w_splith_scale = pack_splith_weight(weight)
+            self.w_splith = wh_.to(device)
         self.scale = (torch.ones(self.cout) if scale is None else scale.detach().float().cpu()).contiguous().to(device)
         self.shift = (torch.zeros(self.cout) if shift is None else shift.detach().float().cpu()).contiguous().to(device)
 
@@ -205,6 +232,8 @@ def _fill_desc(d: ConvDesc, x: View, pc: PackedConv, y: View, relu, relu_upto, r
     d.w_wino = pc.w_wino.data_ptr() if getattr(pc, "w_wino", None) is not None else None
     d.w_wino6 = pc.w_wino6.data_ptr() if getattr(pc, "w_wino6", None) is not None else None
     d.w_split = pc.w_split.data_ptr() if getattr(pc, "w_split", None) is not None else None
+    d.w_splith = pc.w_splith.data_ptr() if getattr(pc, "w_splith", None) is not None else None
+    d.w_splith_scale = float(getattr(pc, "w_splith_scale", 0.0))
     d.scale, d.shift = pc.scale.data_ptr(), pc.shift.data_ptr()
     if res is not None:
         d.res, d.res_cs, d.res_co = res.t.data_ptr(), res.cs, res.co
@@ -233,12 +262,16 @@ FUSE_POOL = os.environ.get("CMK_FUSE_POOL", "1") != "0"      # eSE: average-pool
 PAIR_TOWERS = os.environ.get("CMK_PAIR_TOWERS", "1") != "0"  # FCOS head: conv k of the cls and the bbox tower in one launch (A/B switch)
 ALLOW_SPLIT_BF16 = os.environ.get("CMK_ALLOW_SPLIT_BF16", "0") == "1"   # OPT-IN: pack the bf16-split weights and let the tuner / tables use the
                           # pointwise GEMM's split form (fp32-accurate products from bf16 pieces, cmk.h tune_wm 10).  Off: nothing in the package uses it.
-ALLOW_SPLIT_BF16X3 = os.environ.get("CMK_ALLOW_SPLIT_BF16X3", "0") == "1"   # OPT-IN, a second level: 3x3 stride-1 convs as a direct implicit GEMM on
-                          # TWO bf16 pieces per operand / three products (cmk.h tune_wm 11, tune_sc 2): a 16-bit significand — measured error below the
-                          # fp32 Winograd form's, but not fp32 products.  Off: nothing in the package uses it.
+ALLOW_SPLIT_F16 = os.environ.get("CMK_ALLOW_SPLIT_F16", "0") == "1"   # OPT-IN: pack the fp16 two-piece weights and let the tuner / tables use the direct
+                          # 3x3 form on fp16-split products (cmk.h tune_wm 11, conv_sp3.hip: 22-bit operands, three products, fp32 accumulation —
+                          # the error of an fp32 accumulation).  Off: nothing in the package uses it.
 PACK_WINO6 = True         # pack the F(4x4,3x3) weights too (4x the filter bank per 3x3 stride-1 conv)
 ALLOW_WINOGRAD = True     # let the tuner pick the Winograd F(2x2,3x3) kernel where it is faster (fp32, differs by rounding only)
+TUNE_LOG = []             # (key, {candidate: ms}) per tuned problem
 FORCE_VARIANT = None      # (wm, sc, wn[, splitk]) for every conv launched through the wrappers below (tests, A/B tools); None = table/tuner/default
+TUNE_ONLY = None          # callable(key) -> [(wm, sc, wn, splitk), ...]: the tuner's candidates for that problem instead of the whole menu (targeted
+                          # re-tuning: tools/tune_sp3.py); TUNE_REPS timed launches per candidate, best of TUNE_ROUNDS interleaved rounds
+TUNE_REPS, TUNE_ROUNDS = 2, 1
 AUTOTUNE = False          # when True, the first call of every distinct conv problem times the variant menu (needs an idle, non-capturing stream)
 _TUNED = {}               # problem key -> (wm, sc, wn)
 
@@ -281,7 +314,7 @@ def _variant_on_menu(tv) -> bool:
     if wm == 10:                      # pointwise GEMM from bf16-split products: only where the caller opted in
         return ALLOW_SPLIT_BF16 and sc == 32 and wn == 4 and sk == 1
     if wm == 11:                      # direct 3x3 conv from bf16-split products (conv_sp3.hip): sc = pieces, wn = geometry
-        return ((sc == 3 and ALLOW_SPLIT_BF16) or (sc == 2 and ALLOW_SPLIT_BF16X3)) and 0 <= wn <= 3 and sk == 1
+        return ALLOW_SPLIT_F16 and sc == 2 and 0 <= wn <= 3 and sk == 1
     return (wm in (1, 2, 5, 6, 7, 8, 9) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
 
 
@@ -342,8 +375,8 @@ def _tune(descs, n, key) -> None:
         cands += [(9, 32, mt, sk) for mt in (4, 2) for sk in sks]   # gather form of a 3x3 conv on the pointwise GEMM kernel (conv_pw.hip GA)
         if ALLOW_SPLIT_BF16:
             cands += [(10, 32, 4, 1)]                               # ... and its opt-in bf16-split form
-        if ALLOW_SPLIT_BF16X3:
-            cands += [(11, 2, g, 1) for g in range(4)]              # opt-in: direct 3x3 on two bf16 pieces per operand (conv_sp3.hip), four tile geometries
+        if ALLOW_SPLIT_F16:
+            cands += [(11, 2, g, 1) for g in range(4)]              # opt-in: direct 3x3 on two fp16 pieces per operand (conv_sp3.hip), four tile geometries
     if d0.ksize == 1:
         cands += [(8, 32, mt, sk) for mt in (4, 2) for sk in sks]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
         if ALLOW_SPLIT_BF16:
@@ -354,21 +387,30 @@ def _tune(descs, n, key) -> None:
         cands += [(6, 64, 1, 1), (6, 64, 2, 1)]   # ... its shared-V form: 64 couts per workgroup from one frequency image (conv_wino6s.hip)
         if small and d0.ksize == 3:
             cands += [(6, 16, 1, sk) for sk in (2, 4)]      # ... with the chunk loop split over 2 / 4 workgroups (launches of about one round)
-    for tv in cands:
-        ws = _set_variant(descs, n, tv)
-        if run() != 0:
-            continue                              # not on the menu for this shape
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        run()
-        run()
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1)
-        if ms < best_ms:
-            best, best_ms = (tv[:3] if tv[3] == 1 else tv), ms
-        del ws
+    if TUNE_ONLY is not None:
+        cands = [tuple(tv) + (1,) * (4 - len(tv)) for tv in TUNE_ONLY(key)]
+    times = {}
+    for _ in range(TUNE_ROUNDS):
+        for tv in cands:
+            if times.get(tv) == float("inf"):
+                continue
+            ws = _set_variant(descs, n, tv)
+            if run() != 0:
+                times[tv] = float("inf")          # not on the menu for this shape
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _r in range(TUNE_REPS):
+                run()
+            e1.record()
+            e1.synchronize()
+            times[tv] = min(times.get(tv, float("inf")), e0.elapsed_time(e1) / TUNE_REPS)
+            del ws
+    for tv in cands:                              # first of equals wins, as before
+        if times.get(tv, float("inf")) < best_ms:
+            best, best_ms = (tv[:3] if tv[3] == 1 else tv), times[tv]
     _TUNED[key] = best
+    TUNE_LOG.append((key, {tv: times[tv] for tv in cands if tv in times}))
 
 
 def _default_is_wino6(descs, n, pc) -> bool:
@@ -535,7 +577,7 @@ def conv_gn_multi_pair(xs_a: Sequence[View], pc_a: PackedConv, gn_a, xs_b: Seque
     tv = FORCE_VARIANT if FORCE_VARIANT is not None else _TUNED.get(key)
     if tv is None:
         tv = (6, 16, 1) if _default_is_wino6(half, na, pc_a) else None
-    sp3 = tv is not None and tv[0] == 11 and pc_a.w_split is not None and pc_b.w_split is not None      # opt-in direct bf16-split form
+    sp3 = tv is not None and tv[0] == 11 and pc_a.w_splith is not None and pc_b.w_splith is not None      # opt-in direct fp16-split form
     if tv is None or not (sp3 or (tv[0] == 6 and tv[2] == 1)):
         return None
     _set_variant(descs, n, tv)

@@ -24,8 +24,9 @@ extern "C" {
 #define CMK_EINVAL (-1)   /* bad argument / unsupported shape */
 #define CMK_ELAUNCH (-2)  /* HIP launch error */
 
-int cmk_version(void);                 /* ABI version, currently 4 (2: cmk_conv_desc.w_wino6, cmk_groupnorm_affine_tiles takes record counts;
-                                          3: cmk_conv_desc.pool_ws, cmk_ese_gate_pooled, cmk_pack_records; 4: cmk_conv_desc.w_split) */
+int cmk_version(void);                 /* ABI version, currently 5 (2: cmk_conv_desc.w_wino6, cmk_groupnorm_affine_tiles takes record counts;
+                                          3: cmk_conv_desc.pool_ws, cmk_ese_gate_pooled, cmk_pack_records; 4: cmk_conv_desc.w_split;
+                                          5: cmk_conv_desc.w_splith, w_splith_scale) */
 const char* cmk_arch(void);            /* "gfx950" */
 const char* cmk_last_error(void);
 
@@ -114,6 +115,18 @@ typedef struct {
      * input channels 16*chunk + 8*hh + 0..7 of output channel 32*tile + li (cout_pad = Cout rounded up to 128, zero filled).
      * No caller of this repository selects it by default (ops.ALLOW_SPLIT_BF16); NULL = not available. */
     const void* w_split;
+    /* OPT-IN, tune_wm 11 (conv_sp3.hip; tune_sc = 2 pieces, tune_wn = tile geometry 0..3): a 3x3 stride-1 conv as a DIRECT implicit GEMM on
+     * v_mfma_f32_32x32x16_f16 with every fp32 operand split into TWO fp16 pieces (22 bits of significand: h = fp16(x), m = fp16(x - h), the
+     * residual is exact) and the products m*h, h*m, h*h accumulated in fp32.  The representation error is below an fp32 GEMM's own accumulation
+     * error, so the result carries the error of an fp32 accumulation — NOT the bits of the fp32-MFMA kernels.  Activations are split inside the
+     * kernel (scaled by 2^-4, residual by 2^11: finite up to |x| = 1e6, 22 bits down to 2^-21); the caller packs the weights:
+     * w' = w * S_w, S_w the power of two with max |w'| in [2^14, 2^15); w_splith = 9 x cmk_splith_packed_halves(Cout, Cin) fp16 values,
+     * [tap][Cin/16][cout_pad/32][piece h|m][lane 64][8] (lane = 32*hh + li: input channels 16*chunk + 8*hh + 0..7 of output channel 32*tile + li;
+     * cout_pad = Cout rounded up to 128, zero filled); w_splith_scale = 1 / S_w.  Takes in_scale/in_shift, gn_ws (cmk_conv_gn_records(H, W,
+     * 110 + geometry)), and in cmk_conv2d_nhwc_multi up to 10 problems that may differ in their weights.  No residual, split-K or pooled sums.
+     * No caller of this repository selects it by default (ops.ALLOW_SPLIT_F16); NULL = not available. */
+    const void* w_splith;
+    float w_splith_scale;
 } cmk_conv_desc;
 int cmk_conv2d_nhwc(const cmk_conv_desc* d, void* stream);
 int cmk_conv_pool_rows(const cmk_conv_desc* d);
@@ -131,6 +144,7 @@ int cmk_conv_cout_pad(int Cout);
 int64_t cmk_wino_packed_floats(int Cout, int Cin);
 int64_t cmk_wino6_packed_floats(int Cout, int Cin);
 int64_t cmk_split_packed_halves(int Cout, int Cin);          /* 16-bit elements of cmk_conv_desc.w_split */
+int64_t cmk_splith_packed_halves(int Cout, int Cin);         /* 16-bit elements PER TAP of cmk_conv_desc.w_splith */
 /* spatial tiles per image of the fused-statistics conv (8 x 16 outputs each) */
 int cmk_conv_gn_tiles(int H, int W);
 /* {sum, sumsq} records per image written through cmk_conv_desc.gn_ws by the Winograd kernel tune_wm (5 or 6) on an H x W map */

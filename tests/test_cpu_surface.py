@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                      # loads on CPU; no compute call is made here
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cmk_version() == 4 and lib.cmk_arch() == b"gfx950"
+    assert lib.cmk_version() == 5 and lib.cmk_arch() == b"gfx950"
     assert lib.cmk_conv_cout_pad(80) == 96 and lib.cmk_conv_cout_pad(160) == 160 and lib.cmk_conv_cout_pad(1024) == 1024
     assert lib.cmk_conv_packed_floats(256, 257, 3) == 9 * 17 * 256 * 16
 

@@ -453,3 +453,42 @@ def test_end_to_end_batch8_with_the_opt_in_split_gemm(dev, monkeypatch):
     finally:
         ops._TUNED.clear()
         ops._TUNED.update(saved)
+
+
+def test_end_to_end_batch8_with_the_opt_in_direct_split_convs(dev, monkeypatch):
+    """Second OPT-IN level (ops.ALLOW_SPLIT_F16; nothing selects it by default): on top of the six-product pointwise GEMMs, the 3x3 convs of
+    stage 2 / 3, the FPN outputs, the FCOS towers (fused GroupNorm statistics and input affine) and the mask / mask-IoU heads run as direct
+    implicit GEMMs on TWO fp16 pieces per fp32 operand (cmk.h tune_wm 11, conv_sp3.hip: 22-bit operands, three products, fp32 accumulation) —
+    the measured table `tuned/mi355x_V-39-eSE_b8_800x1280_split3.json`.  The SAME gate as the default path on all eight bench images: labels,
+    ROI locations and their ORDER exact (ORDER_TOL = 0), features / logits / regression / scores / masks within 1e-3 absolute."""
+    import os
+    from centermask2_amd import ops, synthetic as S
+    from .helpers import GOLDEN_ROOT
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16", True)
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_F16", True)
+    model = build_gpu_model()[0]                      # packs the split weights
+    g = golden("e2e_bench8_800x1280")
+    B = int(g["num_images"])
+    saved = dict(ops._TUNED)
+    try:
+        ops._TUNED.clear()
+        n = ops.load_tuned(os.path.join(os.path.dirname(GOLDEN_ROOT), "centermask2_amd", "tuned", "mi355x_V-39-eSE_b8_800x1280_split3.json"))
+        assert n > 0 and sum(1 for v in ops._TUNED.values() if v[0] == 11) >= 8 and sum(1 for v in ops._TUNED.values() if v[0] == 10) >= 9
+        x = S.make_synthetic_images(B, 800, 1280, seed0=int(g["image_seed0"])).to(dev)
+        sizes = [(800, 1280)] * B
+        out = model.inference_padded(x, sizes)
+        feats = model.backbone(x)
+        lg, reg, ctr, _ = model.proposal_generator.fcos_head([feats[k] for k in ("p3", "p4", "p5", "p6", "p7")])
+        torch.cuda.synchronize()
+        res = model.results_from_padded(out, sizes)
+        for i in range(B):
+            r = g["img{}".format(i)]
+            for k in ("p3", "p4", "p5", "p6", "p7"):
+                _probe_check(feats[k][i:i + 1], r[k], 1e-3, "direct-split " + k)
+            for l in range(5):
+                _probe_check(lg[l][i:i + 1], r["logits{}".format(l)], 1e-3, "direct-split logits")
+                _probe_check(reg[l][i:i + 1], r["reg{}".format(l)], 1e-3, "direct-split reg")
+            _check_against_reference_image(res[i], r, "direct-split image {}".format(i), ORDER_TOL)
+    finally:
+        ops._TUNED.clear()
+        ops._TUNED.update(saved)

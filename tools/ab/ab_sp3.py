@@ -27,7 +27,7 @@ import torch
 from centermask2_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 from centermask2_amd import ops
-ops.ALLOW_SPLIT_BF16X3 = True
+ops.ALLOW_SPLIT_F16 = True
 from centermask2_amd.ops import View
 lib = _lib.load(); dev = torch.device("cuda:0"); out = []
 sc = int(sys.argv[3])

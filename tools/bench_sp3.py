@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from centermask2_amd import ops, _lib
 from centermask2_amd.ops import View
-ops.ALLOW_SPLIT_BF16 = ops.ALLOW_SPLIT_BF16X3 = True
+ops.ALLOW_SPLIT_BF16 = ops.ALLOW_SPLIT_F16 = True
 dev = torch.device("cuda:0"); B = 8
 SHAPES = [("stem_2", 400, 640, 64, 64), ("OSA2_x", 200, 320, 128, 128), ("OSA3_0", 100, 160, 256, 160), ("OSA3_x", 100, 160, 160, 160),
           ("OSA4_0", 50, 80, 512, 192), ("OSA4_x", 50, 80, 192, 192), ("OSA5_x", 25, 40, 224, 224),

@@ -8,7 +8,7 @@ h, w, cin, cout, wm, sc, wn = [int(v) for v in sys.argv[1:8]]
 iters = int(sys.argv[8]) if len(sys.argv) > 8 else 3
 B = int(sys.argv[9]) if len(sys.argv) > 9 else 8
 dev = torch.device("cuda:0")
-if wm in (10, 11): ops.ALLOW_SPLIT_BF16 = ops.ALLOW_SPLIT_BF16X3 = True     # the opt-in split forms need their packing
+if wm in (10, 11): ops.ALLOW_SPLIT_BF16 = ops.ALLOW_SPLIT_F16 = True     # the opt-in split forms need their packing
 lib = _lib.load()
 x = View(torch.randn((B, h, w, cin), device=dev)); pc = ops.PackedConv(torch.randn((cout, cin, 3, 3)) * 0.05, None, None, dev)
 y = View(torch.empty((B, h, w, cout), device=dev))
