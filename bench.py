@@ -334,15 +334,15 @@ def split_gemm_leg(body, dev, B, ref_out=None, steps=20, warmup=3, level=1):
             same_counts = bool(torch.equal(out["counts"], ref_out["counts"]))
             same_labels = bool(torch.equal(out["cls"], ref_out["cls"]))
             score_diff = float((out["score"] - ref_out["score"]).abs().max())
-        moved = sum(1 for v in ops._TUNED.values() if v[0] == 10)
+        moved = sum(1 for v in ops._TUNED.values() if v[0] in (10, 12))
         res = {"images_per_sec": round(steps * B / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "body": body,
                "convs_moved": moved, "dtype": "f32 results; the moved convs multiply bf16 pieces (3 per fp32 operand, 6 products per fp32 product) and accumulate in f32",
                "same_detection_counts": same_counts, "same_labels_same_order": same_labels, "max_score_diff_vs_default": score_diff,
                "status": "opt-in (CMK_ALLOW_SPLIT_BF16=1 + a variant table naming tune 10/32/4); not used by `value`"}
         if level >= 2:
             res["convs_3x3_moved"] = sum(1 for v in ops._TUNED.values() if v[0] == 11)
-            res["dtype"] = ("f32 results; the 3x3 convs named by the table multiply 2 fp16 pieces per fp32 operand (22-bit operands, 3 products), the pointwise "
-                            "convs 3 bf16 pieces (6 products); f32 accumulation")
+            res["dtype"] = ("f32 results; the convs named by the table (3x3 direct form, pointwise GEMMs) multiply 2 fp16 pieces per fp32 operand (22-bit operands, "
+                            "3 products per fp32 product); f32 accumulation")
             res["status"] = "opt-in, second level (CMK_ALLOW_SPLIT_F16=1 + tuned/*_split3.json); not used by `value`"
         return res
     finally:

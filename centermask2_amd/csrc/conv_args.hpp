@@ -62,8 +62,8 @@ int launch_wino6(ConvArgs& a, int geo, hipStream_t st);
 int launch_wino6s(ConvArgs& a, int geo, hipStream_t st);
 // conv_pw.hip: 1x1 conv as a GEMM with the weights fetched straight into registers; mt = 4 | 2 accumulator rows per wave
 int launch_pw(ConvArgs& a, int mt, hipStream_t st);
-// conv_pw.hip, opt-in: the same GEMM from bf16-split products (fp32-accurate; a.w = the split packing, cmk.h w_split)
-int launch_pw_split(ConvArgs& a, hipStream_t st);
+// conv_pw.hip, opt-in: the same GEMM from split products (fp32-accurate; mode 1: three bf16 pieces, a.w = cmk.h w_split; 2: two fp16 pieces, w_splith)
+int launch_pw_split(ConvArgs& a, int mode, hipStream_t st);
 // conv_sp3.hip, opt-in: 3x3 stride-1 conv as a direct implicit GEMM on fp16-split products (halo tile in LDS, 2 pieces per operand, geo 0..3)
 int launch_sp3(ConvArgs& a, int geo, int pieces, hipStream_t st);
 

@@ -907,6 +907,7 @@ static int pointwise_mt(const cmk_conv_desc* d, int n) {
     if (d->res_mode == 2 && ((d->W & 1) || d->pool_ws || (long)d->N * d->Hr * d->Wr * d->res_cs * 4 >= (1L << 31))) return 0;     // FPN top-down add: even widths
     if (d->tune_wm == 8) return (d->tune_wn == 4 || d->tune_wn == 2) ? d->tune_wn : 0;
     if (d->tune_wm == 10) return (d->w_split && d->tune_wn == 4 && d->res_mode != 1 && d->splitk <= 1) ? 4 : 0;      // the bf16-split form: the 256-pixel tile
+    if (d->tune_wm == 12) return (d->w_splith && d->tune_wn == 4 && d->res_mode != 1 && d->splitk <= 1) ? 4 : 0;     // the fp16-split form
     if (d->tune_wm || d->tune_sc || d->tune_wn) return 0;
     const long ctiles = cdiv(cout32, 4);
     const long wg2 = ((total_pix + 127) / 128) * ctiles, wg4 = ((total_pix + 255) / 256) * ctiles;
@@ -925,6 +926,7 @@ static int gather_mt(const cmk_conv_desc* d, int n) {
     if (d->splitk > 1 && (d->tune_wm != 9 || !d->splitk_ws || (9 * (d->Cin >> 4)) % (2 * d->splitk))) return 0;
     if (d->tune_wm == 9) return (d->tune_wn == 4 || d->tune_wn == 2) ? d->tune_wn : 0;
     if (d->tune_wm == 10) return (d->w_split && d->tune_wn == 4 && d->res_mode == 0 && d->splitk <= 1) ? 4 : 0;      // the bf16-split gather form
+    if (d->tune_wm == 12) return (d->w_splith && d->tune_wn == 4 && d->res_mode == 0 && d->splitk <= 1) ? 4 : 0;     // the fp16-split gather form
     if (d->tune_wm || d->tune_sc || d->tune_wn || d->stride != 2) return 0;
     const long ctiles = cdiv(cout32, 4);
     const long wg4 = ((out_pix + 255) / 256) * ctiles;
@@ -1010,7 +1012,17 @@ static int run(const cmk_conv_desc* descs, int n, void* stream) {
         a.w = reinterpret_cast<const float*>(d->w_split);
         a.ksplit = 1;
         a.ga_stride = d->ksize == 3 ? d->stride : 0;
-        return launch_pw_split(a, st);
+        return launch_pw_split(a, 1, st);
+    }
+    if (d->tune_wm == 12) {                            // opt-in: the same on two fp16 pieces per operand / three products (cmk.h w_splith)
+        if (!(d->ksize == 1 ? pointwise_mt(d, n) : gather_mt(d, n)) || !(d->w_splith_scale > 0.f))
+            return fail(CMK_EINVAL, "conv: the fp16-split variant needs w_splith, w_splith_scale and a conv the pointwise GEMM kernel takes (1x1, or 3x3 in its gather form)%s", "");
+        a.cout_pad = cdiv(cout32, 4) * 128;
+        a.w = reinterpret_cast<const float*>(d->w_splith);
+        a.p[0].acc_scale = d->w_splith_scale;
+        a.ksplit = 1;
+        a.ga_stride = d->ksize == 3 ? d->stride : 0;
+        return launch_pw_split(a, 2, st);
     }
     if (d->tune_wm == 11) {                            // opt-in: direct 3x3 conv on bf16-split products (conv_sp3.hip); tune_sc = pieces, tune_wn = geometry
         if (d->ksize != 3 || d->stride != 1 || !d->w_splith || d->splitk > 1 || d->res_mode != 0 || d->in_relu || d->pool_ws)

@@ -49,9 +49,14 @@ __device__ f32x4 pw_buffer_load(i32x4 rsrc, int voffset, int soffset, int aux) _
 // and are split while they are staged (global -> registers -> split -> LDS as [32-row block][piece][lane][8 bf16], the MFMA's A operand
 // layout: one ds_read_b128 per piece and block); the weights are split once on the host (a.w: [K/16][cout_pad/32][piece 3][lane 64][8 bf16]).
 // The accumulator layout is the fp32 kernel's, so the epilogue (scale/shift/ReLU, stores, POOL sums) is shared.
-template <int MT, bool POOL, bool GA, bool UPRES, bool SPLITK, bool SPLIT = false>
+// SPLIT 2 (opt-in, cmk.h tune_wm 12): the same GEMM on TWO FP16 pieces per operand — 22 bits of significand, three products m*h, h*m, h*h (what
+// is dropped is 2^-22 of a product), half the MFMAs of the bf16 form for the same fp32-class error; fp16's exponent range is met by exact
+// power-of-two scaling as in conv_sp3.hip (activations x 2^-4, their residual x 2^11 and the weight piece it meets x 2^-11 in registers; the
+// weights x S_w on the host, a.p[0].acc_scale = 1 / S_w; the accumulator x 2^4 / S_w folded into the epilogue's per-channel scale).
+// a.w: [K/16][cout_pad/32][piece 2][lane 64][8 fp16] (cmk.h w_splith).
+template <int MT, bool POOL, bool GA, bool UPRES, bool SPLITK, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
-    static_assert(!SPLIT || (MT == 4 && !SPLITK && !(GA && (UPRES || POOL))), "the split form: the 256 x 128 tile, no split-K");
+    static_assert(!SPLIT || (MT == 4 && !SPLITK && !(GA && (UPRES || POOL))), "the split forms: the 256 x 128 tile, no split-K");
     constexpr int BM = 64 * MT;         // pixels per workgroup
     constexpr int ABUF = BM * PST;      // floats per LDS buffer (rows of 16 channels, pitch 20)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -182,7 +187,81 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
         for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT == 2) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr float SX = 0.0625f, RS = 2048.f;              // activation scale 2^-4, residual scale 2^11
+        constexpr int STAGE = (BM / 32) * 2 * 64 * 16;          // bytes per LDS stage: [row block][piece][lane][8 fp16]
+        unsigned char* sb = reinterpret_cast<unsigned char*>(smem);
+        auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, f16x2{(_Float16)x, (_Float16)y}); };       // round to nearest even
+        auto unpk = [](unsigned p_) { const f16x2 h_ = __builtin_bit_cast(f16x2, p_); return f32x2{(float)h_.x, (float)h_.y}; };
+        int st_off[MT];
+#pragma unroll
+        for (int it = 0; it < MT; ++it) {
+            const int r = (tid >> 2) + 64 * it;
+            st_off[it] = (((r >> 5) * 2) * 64 + ((tid & 3) >> 1) * 32 + (r & 31)) * 16 + (tid & 1) * 8;
+        }
+        auto stage = [&](int buf) {
+            unsigned char* dst = sb + buf * STAGE;
+#pragma unroll
+            for (int it = 0; it < MT; ++it) {
+                const f32x4 x = a_st[it] * SX;
+                u32x2 h, m_;
+                h.x = pk(x.x, x.y); h.y = pk(x.z, x.w);
+                const f32x2 h01 = unpk(h.x), h23 = unpk(h.y);
+                const f32x4 r1 = f32x4{x.x - h01.x, x.y - h01.y, x.z - h23.x, x.w - h23.y} * RS;      // exact: h holds the leading bits of x
+                m_.x = pk(r1.x, r1.y); m_.y = pk(r1.z, r1.w);
+                *reinterpret_cast<u32x2*>(dst + st_off[it]) = h;
+                *reinterpret_cast<u32x2*>(dst + st_off[it] + 64 * 16) = m_;
+            }
+        };
+        const u32x4* wsp = reinterpret_cast<const u32x4*>(a.w) + ((long)(co0 >> 5) * 2) * 64 + lane;      // wave-uniform base + lane
+        const long wstep = (long)(a.cout_pad >> 5) * 2 * 64;
+        u32x4 wb[2][2];
+        auto load_Bs = [&](int chunk) {
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int p_ = 0; p_ < 2; ++p_) wb[nn][p_] = wsp[chunk * wstep + (nn * 2 + p_) * 64];
+        };
+        load_A(0);
+        load_Bs(0);
+        stage(0);
+        load_A(min(1, nchunks - 1));
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();            // stage c & 1 is complete; everybody has read all of the other stage
+            const u32x4* ap = reinterpret_cast<const u32x4*>(sb + (c & 1) * STAGE) + (wm * MT * 2) * 64 + lane;
+            f16x8 Bh[2], Bm[2], Bhs[2];
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) {
+                Bh[nn] = __builtin_bit_cast(f16x8, wb[nn][0]);
+                Bm[nn] = __builtin_bit_cast(f16x8, wb[nn][1]);
+                Bhs[nn] = Bh[nn] * (_Float16)(1.f / RS);        // meets the activations' scaled residual
+            }
+            load_Bs(min(c + 1, nchunks - 1));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const u32x4 ah = ap[(m * 2 + 0) * 64], am = ap[(m * 2 + 1) * 64];
+                if (m == 1) {           // the next chunk's activations (in registers since the last chunk) are split between the MFMA groups
+                    stage((c + 1) & 1);
+                    load_A(min(c + 2, nchunks - 1));
+                }
+                const f16x8 Ah = __builtin_bit_cast(f16x8, ah), Am = __builtin_bit_cast(f16x8, am);
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    f32x16 cacc = acc[m][nn];
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Am, Bhs[nn], cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bm[nn], cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[nn], cacc, 0, 0, 0);
+                    acc[m][nn] = cacc;
+                }
+            }
+        }
+        __syncthreads();                // the epilogue may reuse the LDS
+    } else if constexpr (SPLIT == 1) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -400,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
             const int co = co0 + nn * 32 + li;
             const bool cvalid = INTERIOR || co < a.Cout;
             float sc = cvalid ? P.scale[co] : 0.f;
+            if constexpr (SPLIT == 2) sc *= P.acc_scale * 16.f;         // 1 / (S_x * S_w)
             float sh = cvalid ? P.shift[co] : 0.f;
             const float lo = co < a.relu_upto ? 0.f : __builtin_nanf("");      // max(v, NaN) = v: lanes without the ReLU
             // the values are waited for once, here; the compiler cannot see through the asm and so does not put a full wait in front
@@ -506,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int MT, bool POOL, bool GA, bool UPRES = false, bool SPLITK = false, bool SPLIT = false>
+template <int MT, bool POOL, bool GA, bool UPRES = false, bool SPLITK = false, int SPLIT = 0>
 static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * MT;
 #ifdef PW_TRACE
@@ -521,7 +601,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     });
     if (rc0) return rc0;
 #else
-    constexpr int LDS_BYTES = SPLIT ? 2 * (BM / 32) * 3 * 64 * 16 : 2 * BM * PST * 4;       // 40 KB (MT 4) / 20 KB (MT 2) / 48 KB (split): under the 64 KB a kernel gets without an attribute
+    constexpr int LDS_BYTES = SPLIT ? 2 * (BM / 32) * (SPLIT == 2 ? 2 : 3) * 64 * 16 : 2 * BM * PST * 4;       // 40 KB (MT 4) / 20 KB (MT 2) / 48 | 32 KB (split): under the 64 KB a kernel gets without an attribute
 #endif
     ConvProblem& p = a.p[0];
     p.tile_begin = 0;
@@ -573,8 +653,10 @@ int launch_pw(ConvArgs& a, int mt, hipStream_t st) {
     return fail(CMK_EINVAL, "conv_pw: tile height must be 4 or 2%s", "");
 }
 
-// The bf16-split form (cmk.h tune_wm 10): a.w is the split packing; plain 1x1 conv, optionally with the pooled sums.
-int launch_pw_split(ConvArgs& a, hipStream_t st) {
+// The split forms (cmk.h tune_wm 10: three bf16 pieces, six products; 12: two fp16 pieces, three products): a.w is the split packing; plain 1x1
+// conv, optionally with the pooled sums / the upsampled residual, or a 3x3 conv in the gather form.
+template <int SPLIT>
+static int launch_pw_split_mode(ConvArgs& a, hipStream_t st) {
     const ConvProblem& p = a.p[0];
     if (a.nprob != 1 || p.in_scale || a.in_relu || a.gn_ws || a.ksplit > 1 || a.res_mode == 1)
         return fail(CMK_EINVAL, "conv_pw (split): one problem, no input affine / input ReLU / GroupNorm statistics / split-K / same-size residual%s", "");
@@ -584,15 +666,20 @@ int launch_pw_split(ConvArgs& a, hipStream_t st) {
     if ((long)(64 * 4 + 8) * a.y_cs >= (1L << 30) || (long)(64 * 4 + 8) * a.res_cs >= (1L << 30)) return fail(CMK_EINVAL, "conv_pw (split): output row too wide%s", "");
     if (a.ga_stride) {              // 3x3 conv (stride 1 | 2) as the gather GEMM over 9 taps
         if (a.pool_ws || a.res_mode || p.H >= 32768 || p.W >= 32768) return fail(CMK_EINVAL, "conv_pw (split): gather form: no pooled sums / residual, maps below 32768 x 32768%s", "");
-        return launch_pw_mt<4, false, true, false, false, true>(a, st);
+        return launch_pw_mt<4, false, true, false, false, SPLIT>(a, st);
     }
     if (a.res_mode == 2) {          // FPN top-down add in the epilogue
         if (a.pool_ws || (p.Wo & 1) || (long)p.N * a.Hr * a.Wr * a.res_cs * 4 >= (1L << 31))
             return fail(CMK_EINVAL, "conv_pw (split): the upsampled residual needs an even output width, no pooled sums, a residual below 2 GiB%s", "");
-        return launch_pw_mt<4, false, false, true, false, true>(a, st);
+        return launch_pw_mt<4, false, false, true, false, SPLIT>(a, st);
     }
     if (a.pool_ws && (long)p.Ho * p.Wo < 128) return fail(CMK_EINVAL, "conv_pw (split): pooled sums need H*W >= 128%s", "");
-    return a.pool_ws ? launch_pw_mt<4, true, false, false, false, true>(a, st) : launch_pw_mt<4, false, false, false, false, true>(a, st);
+    return a.pool_ws ? launch_pw_mt<4, true, false, false, false, SPLIT>(a, st) : launch_pw_mt<4, false, false, false, false, SPLIT>(a, st);
+}
+
+int launch_pw_split(ConvArgs& a, int mode, hipStream_t st) {
+    if (mode == 2 && !(a.p[0].acc_scale > 0.f)) return fail(CMK_EINVAL, "conv_pw (split): w_splith_scale missing%s", "");
+    return mode == 2 ? launch_pw_split_mode<2>(a, st) : launch_pw_split_mode<1>(a, st);
 }
 
 }  // namespace cmk

@@ -169,7 +169,7 @@ def pack_split_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack_splith_weight(w: torch.Tensor):
-    """(Cout, Cin, 3, 3) fp32 -> (the fp16 two-piece packing of cmk_conv_desc.w_splith, 1 / S_w) for the opt-in direct form (tune_wm 11):
+    """(Cout, Cin, k, k) fp32, k = 1 | 3 -> (the fp16 two-piece packing of cmk_conv_desc.w_splith, 1 / S_w) for the opt-in fp16-split forms (tune_wm 11, 12):
     w' = w * S_w with S_w the power of two that puts max |w'| in [2^14, 2^15); pieces h = fp16(w'), m = fp16(w' - h) (the residual is exact in
     fp32); laid out [tap][Cin/16][cout_pad/32][piece][lane = 32*hh + li][8]: input channel 16*chunk + 8*hh + e of output channel 32*tile + li;
     cout_pad = Cout rounded up to 128, zero filled."""
@@ -180,15 +180,16 @@ def pack_splith_weight(w: torch.Tensor):
     wf = w.detach().float().cpu()
     amax = float(wf.abs().max())
     s_w = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
-    full = torch.zeros((cout_pad, 9, cin_pad), dtype=torch.float32)
-    full[:cout, :, :cin] = wf.permute(0, 2, 3, 1).reshape(cout, 9, cin) * s_w
+    taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
+    full = torch.zeros((cout_pad, taps, cin_pad), dtype=torch.float32)
+    full[:cout, :, :cin] = wf.reshape(cout, cin, taps).permute(0, 2, 1) * s_w
     h = full.to(torch.float16)
     m = (full - h.float()).to(torch.float16)
-    st = torch.stack([h, m], 0)                                                     # (2, cout_pad, 9, cin_pad)
-    r = st.reshape(2, cout_pad // 32, 32, 9, cin_pad // 16, 2, 8)                   # [piece][tile][li][tap][chunk][hh][e]
+    st = torch.stack([h, m], 0)                                                     # (2, cout_pad, taps, cin_pad)
+    r = st.reshape(2, cout_pad // 32, 32, taps, cin_pad // 16, 2, 8)                # [piece][tile][li][tap][chunk][hh][e]
     r = r.permute(3, 4, 1, 0, 5, 2, 6).contiguous()                                 # [tap][chunk][tile][piece][hh][li][e]
-    assert r.numel() == 9 * lib.cmk_splith_packed_halves(cout, cin_pad)
-    return r.reshape(9, cin_pad // 16, cout_pad // 32, 2, 64, 8), 1.0 / s_w
+    assert r.numel() == taps * lib.cmk_splith_packed_halves(cout, cin_pad)
+    return r.reshape(taps, cin_pad // 16, cout_pad // 32, 2, 64, 8), 1.0 / s_w
 
 
 class PackedConv:
@@ -210,7 +211,7 @@ class PackedConv:
             (self.k == 1 and self.cout > 224) or (self.k == 3 and (self.cout > 224 or 96 < self.cout <= 128)))) else None
         # opt-in (ALLOW_SPLIT_F16): the fp16 two-piece packing for the direct 3x3 form (cmk.h tune_wm 11)
         self.w_splith, self.w_splith_scale = None, 0.0
-        if ALLOW_SPLIT_F16 and self.k == 3 and stride == 1 and self.cin >= 32:
+        if ALLOW_SPLIT_F16 and self.cin >= 32 and (self.k == 3 or (self.k == 1 and self.cout > 224 and self.cin_pad % 32 == 0)):
             wh_, self.w_splith_scale = pack_splith_weight(weight)
             self.w_splith = wh_.to(device)
         self.scale = (torch.ones(self.cout) if scale is None else scale.detach().float().cpu()).contiguous().to(device)
@@ -313,6 +314,8 @@ def _variant_on_menu(tv) -> bool:
         return wn in (1, 2) and sk == 1
     if wm == 10:                      # pointwise GEMM from bf16-split products: only where the caller opted in
         return ALLOW_SPLIT_BF16 and sc == 32 and wn == 4 and sk == 1
+    if wm == 12:                      # pointwise GEMM from fp16-split products (two pieces, three products)
+        return ALLOW_SPLIT_F16 and sc == 32 and wn == 4 and sk == 1
     if wm == 11:                      # direct 3x3 conv from bf16-split products (conv_sp3.hip): sc = pieces, wn = geometry
         return ALLOW_SPLIT_F16 and sc == 2 and 0 <= wn <= 3 and sk == 1
     return (wm in (1, 2, 5, 6, 7, 8, 9) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
@@ -376,11 +379,14 @@ def _tune(descs, n, key) -> None:
         if ALLOW_SPLIT_BF16:
             cands += [(10, 32, 4, 1)]                               # ... and its opt-in bf16-split form
         if ALLOW_SPLIT_F16:
+            cands += [(12, 32, 4, 1)]                               # ... and the fp16 two-piece form of the gather GEMM
             cands += [(11, 2, g, 1) for g in range(4)]              # opt-in: direct 3x3 on two fp16 pieces per operand (conv_sp3.hip), four tile geometries
     if d0.ksize == 1:
         cands += [(8, 32, mt, sk) for mt in (4, 2) for sk in sks]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
         if ALLOW_SPLIT_BF16:
             cands += [(10, 32, 4, 1)]                               # ... its opt-in bf16-split form (the library refuses it where it does not apply)
+        if ALLOW_SPLIT_F16:
+            cands += [(12, 32, 4, 1)]                               # ... its opt-in fp16-split form (two pieces, three products)
     if ALLOW_WINOGRAD:
         cands += [(5, 16, 2, 1)]                  # fused Winograd F(2x2,3x3)
         cands += [(6, 16, 1, 1), (6, 16, 2, 1)]   # fused Winograd F(4x4,3x3): map tiles / pairs of RoI maps (the library rejects what does not apply)
@@ -978,13 +984,13 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False) -> str:
     wm, sc, wn = tv[:3]
     sk = "true" if (len(tv) > 3 and tv[3] > 1) else "false"
     if wm == 8:
-        return "conv_pw_kernel<{}, {}, false, {}, {}, false>".format(wn, "true" if pool else "false", "true" if upres else "false", sk)
-    if wm == 10:
-        return "conv_pw_kernel<4, {}, {}, {}, false, true>".format("true" if pool else "false", "true" if taps == 9 else "false", "true" if upres else "false")
+        return "conv_pw_kernel<{}, {}, false, {}, {}, 0>".format(wn, "true" if pool else "false", "true" if upres else "false", sk)
+    if wm in (10, 12):
+        return "conv_pw_kernel<4, {}, {}, {}, false, {}>".format("true" if pool else "false", "true" if taps == 9 else "false", "true" if upres else "false", 1 if wm == 10 else 2)
     if wm == 11:
         return "conv_sp3_kernel<{}, 2, {}, {}>".format(wn, sc, "true" if aff else "false")
     if wm == 9:
-        return "conv_pw_kernel<{}, false, true, false, {}, false>".format(wn, sk)
+        return "conv_pw_kernel<{}, false, true, false, {}, 0>".format(wn, sk)
     if wm == 7:
         return "conv_igemm_kernel<1, 1, 1, {}, 32, true>".format(wn)
     return "conv_igemm_kernel<{}, {}, {}, {}, {}, false>".format(taps, stride, wm, wn, 32 if taps == 1 else sc)

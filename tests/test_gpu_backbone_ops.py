@@ -646,25 +646,27 @@ def test_tower_pair_launch_equals_two_launches(dev, sc, with_affine, monkeypatch
 
 @pytest.mark.parametrize("case", [(2, 13, 19, 96, 256, False), (1, 25, 40, 2144, 1024, True), (1, 16, 16, 64, 320, False), (1, 64, 64, 768, 256, True),
                                   (2, 10, 13, 160, 512, True)])
-def test_conv_pointwise_split_bf16_form(dev, case, monkeypatch):
-    """OPT-IN tune_wm 10: the pointwise GEMM with every fp32 product rebuilt from three bf16 pieces per operand (six products, fp32
-    accumulation) — checked against a FLOAT64 convolution at 2e-5 absolute (the fp32-MFMA kernel's own distance from float64 on these
-    shapes), ragged pixel counts, cout padding, channel views via the packed conv, and the pooled sums of the eSE gate; refused without
-    the split packing."""
+@pytest.mark.parametrize("form", [10, 12])
+def test_conv_pointwise_split_bf16_form(dev, case, form, monkeypatch):
+    """OPT-IN tune_wm 10 / 12: the pointwise GEMM with every fp32 product rebuilt from three bf16 pieces per operand (six products) or from two
+    fp16 pieces (22-bit operands, three products), fp32 accumulation — checked against a FLOAT64 convolution at 2e-5 absolute (the fp32-MFMA
+    kernel's own distance from float64 on these shapes), ragged pixel counts, cout padding, channel views via the packed conv, and the pooled
+    sums of the eSE gate; refused without the split packing."""
     import ctypes
     from centermask2_amd import _lib
     n, h, w, cin, cout, pool = case
-    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16", True)
+    flag = "ALLOW_SPLIT_BF16" if form == 10 else "ALLOW_SPLIT_F16"
+    monkeypatch.setattr(ops, flag, True)
     x = _rand((n, cin, h, w), 301).abs()                      # post-ReLU-like inputs
     wt = _rand((cout, cin, 1, 1), 302, (2.0 / cin) ** 0.5)
     scale = torch.rand(cout, generator=torch.Generator().manual_seed(303)) + 0.5
     shift = _rand((cout,), 304, 0.1)
     ref = F.relu(F.conv2d(x.double(), wt.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
     pc = ops.PackedConv(wt, scale, shift, dev)
-    assert pc.w_split is not None
+    assert (pc.w_split if form == 10 else pc.w_splith) is not None
     xv = ops.as_view(x.to(dev))
     ys = {}
-    for tv in ((10, 32, 4), (8, 32, 4)):
+    for tv in ((form, 32, 4), (8, 32, 4)):
         y = View(torch.full((n, h, w, cout), -5.0, device=dev))
         d = (_lib.ConvDesc * 1)()
         ops._fill_desc(d[0], xv, pc, y, True, None, None, False, False)
@@ -678,39 +680,40 @@ def test_conv_pointwise_split_bf16_form(dev, case, monkeypatch):
         _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "pointwise " + str(tv))
         torch.cuda.synchronize()
         ys[tv[0]] = (y, pws)
-    err_split = float((ys[10][0].nchw().cpu().double() - ref).abs().max())
+    err_split = float((ys[form][0].nchw().cpu().double() - ref).abs().max())
     err_f32 = float((ys[8][0].nchw().cpu().double() - ref).abs().max())
     assert err_split <= 2e-5 and err_split <= 4.0 * err_f32 + 1e-6, (err_split, err_f32)
     if pool:                                                   # the same records (sums of the stored values) up to the values' own rounding
-        a, b = ys[10][1].cpu().double(), ys[8][1].cpu().double()
+        a, b = ys[form][1].cpu().double(), ys[8][1].cpu().double()
         assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
     # without the split packing the variant is refused, not silently replaced
-    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16", False)
+    monkeypatch.setattr(ops, flag, False)
     pc2 = ops.PackedConv(wt, scale, shift, dev)
     d = (_lib.ConvDesc * 1)()
     ops._fill_desc(d[0], xv, pc2, View(torch.empty((n, h, w, cout), device=dev)), True, None, None, False, False)
-    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 10, 32, 4
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = form, 32, 4
     assert _lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
 
 
-def test_conv_split_bf16_gather_and_upsampled_residual_forms(dev, monkeypatch):
-    """OPT-IN tune_wm 10 beyond the plain 1x1 conv: a 3x3 conv (stride 2 and stride 1) in the gather form — K walks 9 taps x Cin / 16 chunks, the split
+@pytest.mark.parametrize("form", [10, 12])
+def test_conv_split_bf16_gather_and_upsampled_residual_forms(dev, form, monkeypatch):
+    """OPT-IN tune_wm 10 / 12 (three bf16 pieces / two fp16 pieces per operand) beyond the plain 1x1 conv: a 3x3 conv (stride 2 and stride 1) in the gather form — K walks 9 taps x Cin / 16 chunks, the split
     weights packed tap-major — and a 1x1 lateral with the nearest-2x upsampled residual in the epilogue (d2 FPN top-down add); against float64."""
     import ctypes
     from centermask2_amd import _lib
-    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16", True)
+    monkeypatch.setattr(ops, "ALLOW_SPLIT_BF16" if form == 10 else "ALLOW_SPLIT_F16", True)
     for (n, h, w, cin, cout, stride) in ((2, 21, 35, 64, 128, 2), (1, 17, 23, 32, 256, 1)):
         x = _rand((n, cin, h, w), 311).abs()
         wt = _rand((cout, cin, 3, 3), 312, (2.0 / (cin * 9)) ** 0.5)
         bias = _rand((cout,), 313, 0.1)
         ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), stride=stride, padding=1))
         pc = ops.PackedConv(wt, None, bias, dev, stride=stride)
-        assert pc.w_split is not None
+        assert (pc.w_split if form == 10 else pc.w_splith) is not None
         ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
         y = View(torch.full((n, ho, wo, cout), -5.0, device=dev))
         d = (_lib.ConvDesc * 1)()
         ops._fill_desc(d[0], ops.as_view(x.to(dev)), pc, y, True, None, None, False, False)
-        d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 10, 32, 4
+        d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = form, 32, 4
         _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "split gather form")
         torch.cuda.synchronize()
         assert float((y.nchw().cpu().double() - ref).abs().max()) <= 2e-5
@@ -725,7 +728,7 @@ def test_conv_split_bf16_gather_and_upsampled_residual_forms(dev, monkeypatch):
     y = View(torch.empty((n, h, w, cout), device=dev))
     d = (_lib.ConvDesc * 1)()
     ops._fill_desc(d[0], ops.as_view(x.to(dev)), pc, y, False, None, ops.as_view(coarse.to(dev)), True, False)
-    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 10, 32, 4
+    d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = form, 32, 4
     _lib.check(_lib.load().cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "split lateral + upsampled residual")
     torch.cuda.synchronize()
     assert float((y.nchw().cpu().double() - ref).abs().max()) <= 2e-5

@@ -456,7 +456,7 @@ def test_end_to_end_batch8_with_the_opt_in_split_gemm(dev, monkeypatch):
 
 
 def test_end_to_end_batch8_with_the_opt_in_direct_split_convs(dev, monkeypatch):
-    """Second OPT-IN level (ops.ALLOW_SPLIT_F16; nothing selects it by default): on top of the six-product pointwise GEMMs, the 3x3 convs of
+    """Second OPT-IN level (ops.ALLOW_SPLIT_F16; nothing selects it by default): the pointwise GEMMs (tune_wm 12) and the 3x3 convs of
     stage 2 / 3, the FPN outputs, the FCOS towers (fused GroupNorm statistics and input affine) and the mask / mask-IoU heads run as direct
     implicit GEMMs on TWO fp16 pieces per fp32 operand (cmk.h tune_wm 11, conv_sp3.hip: 22-bit operands, three products, fp32 accumulation) —
     the measured table `tuned/mi355x_V-39-eSE_b8_800x1280_split3.json`.  The SAME gate as the default path on all eight bench images: labels,
@@ -473,7 +473,7 @@ def test_end_to_end_batch8_with_the_opt_in_direct_split_convs(dev, monkeypatch):
     try:
         ops._TUNED.clear()
         n = ops.load_tuned(os.path.join(os.path.dirname(GOLDEN_ROOT), "centermask2_amd", "tuned", "mi355x_V-39-eSE_b8_800x1280_split3.json"))
-        assert n > 0 and sum(1 for v in ops._TUNED.values() if v[0] == 11) >= 8 and sum(1 for v in ops._TUNED.values() if v[0] == 10) >= 9
+        assert n > 0 and sum(1 for v in ops._TUNED.values() if v[0] == 11) >= 6 and sum(1 for v in ops._TUNED.values() if v[0] == 12) >= 9
         x = S.make_synthetic_images(B, 800, 1280, seed0=int(g["image_seed0"])).to(dev)
         sizes = [(800, 1280)] * B
         out = model.inference_padded(x, sizes)

@@ -14,9 +14,9 @@ ops.ALLOW_SPLIT_BF16 = ops.ALLOW_SPLIT_F16 = True
 ops._TUNED.clear()
 ops.load_tuned(os.path.join(bench.ROOT, "centermask2_amd", "tuned", "mi355x_{}_b{}_800x1280.json".format(body, B)))
 moved = 0
-for k, v in list(ops._TUNED.items()):            # the six-product forms of the pointwise kernel, as bench.py's split_gemm leg takes them
+for k, v in list(ops._TUNED.items()):            # every conv the pointwise GEMM kernel runs without split-K: its fp16 two-piece form (tune 12)
     if len(v) == 3 and ((k[0] == 1 and v[0] == 8 and k[6] in (0, 2)) or (k[0] == 3 and v[0] == 9 and k[6] == 0)):
-        ops._TUNED[k] = (10, 32, 4); moved += 1
+        ops._TUNED[k] = (12, 32, 4); moved += 1
 incumbent = {k: v for k, v in ops._TUNED.items() if k[0] == 3 and k[1] == 1}
 for k in incumbent: del ops._TUNED[k]
 ops.TUNE_ONLY = lambda key: [incumbent[key]] + [(11, 2, g) for g in range(4)] if key in incumbent else [(0, 0, 0)]
@@ -40,4 +40,4 @@ for key, times in ops.TUNE_LOG:
     won += keep[0] == 11
     print("%-90s inc %s %.3f | %s | -> %s" % (ops._key_to_str(key), incumbent[key], t_inc, " ".join("g%d %.3f" % (tv[2], ms) for tv, ms in times.items() if tv[0] == 11), ops._TUNED[key]), flush=True)
 ops.save_tuned(out)
-print("3x3 problems: %d, moved to the direct split form: %d; pointwise convs on the six-product form: %d; table: %s" % (len(incumbent), won, moved, out))
+print("3x3 problems: %d, moved to the direct split form: %d; pointwise convs on the fp16 two-piece form: %d; table: %s" % (len(incumbent), won, moved, out))
