@@ -553,6 +553,7 @@ def main():
                 result["split_direct3x3"] = split_gemm_leg(args.body, dev, B, out, level=2)
                 if args.body == "V-39-eSE":
                     result["split_gemm_v99"] = split_gemm_leg("V-99-eSE", dev, B, None, steps=5, warmup=2)
+                    result["split_direct3x3_v99"] = split_gemm_leg("V-99-eSE", dev, B, None, steps=5, warmup=2, level=2)
             if cpu is not None:
                 result["cpu_baseline"] = cpu
                 result["ap_delta"] = ap
