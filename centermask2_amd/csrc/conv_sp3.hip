@@ -62,10 +62,15 @@ struct SP3L {
     static constexpr int ITEMS = HR * HC * 4;                       // float4 loads per chunk
     static constexpr int IT = (ITEMS + 255) / 256;
     static constexpr int LDS_BYTES = 2 * STAGE;
+#ifdef SP3_TRACE
+    static constexpr int LDS_ALLOC = LDS_BYTES + 4 * 128 * 8;
+#else
+    static constexpr int LDS_ALLOC = LDS_BYTES;
+#endif
 };
 
 #ifndef SP3_ABL
-#define SP3_ABL 0      // timing ablations (results wrong): 1 no activation loads, 2 no split / LDS writes, 4 no weight loads, 8 no A reads, 16 no MFMAs, 32 no stores, 64 all weight requests to the same lines
+#define SP3_ABL 0      // timing ablations (results wrong): 1 no activation loads, 2 no split / LDS writes, 4 no weight loads, 8 no A reads, 16 no MFMAs, 32 no stores, 64 all weight requests to the same lines, 128 no 2^-11 multiply of the weight piece
 #endif
 
 template <int GEO, int NB, int P, bool AFF>
@@ -175,7 +180,17 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
     };
 
     // ---- weights: wave-uniform base + lane ----------------------------------------------------------------------------------------------------
-    const u32x4* wsp = reinterpret_cast<const u32x4*>(Pb.w) + lane;      // (problems of one launch may differ in weights: the two FCOS towers)
+    // (problems of one launch may differ in weights: the two FCOS towers)  Buffer loads: the lane offset is the only vector operand, the
+    // position of the (tap, chunk, cout tile, piece) KiB is a scalar offset — no 64-bit vector address arithmetic per request
+    sp3_i32x4 wrsrc;
+    {
+        const unsigned long long base = (unsigned long long)Pb.w;
+        wrsrc.x = __builtin_amdgcn_readfirstlane((int)(base & 0xffffffffull));
+        wrsrc.y = __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffull));
+        wrsrc.z = __builtin_amdgcn_readfirstlane(9 * nchunks * nblocks * P * 1024);       // < 2^31 (host)
+        wrsrc.w = 0x00020000;
+    }
+    const int wlane = lane * 16;
     int wblk[NB];
 #pragma unroll
     for (int nn = 0; nn < NB; ++nn) wblk[nn] = ((SP3_ABL & 64) ? nn : min(cb0 + nn, nblocks - 1)) * P * 64;       // (tiles past cout_pad: any valid block, never stored)
@@ -192,7 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
 #endif
 #pragma unroll
         for (int j = 0; j < NB * P; ++j)
-            if (part < 0 || part == j) wq[set][j / P][j % P] = wsp[k + wblk[j / P] + (j % P) * 64];
+            if (part < 0 || part == j)
+                wq[set][j / P][j % P] = __builtin_bit_cast(u32x4, sp3_buffer_load(wrsrc, wlane, (int)(k + wblk[j / P] + (j % P) * 64) * 16, 0));
 #endif
     };
 
@@ -205,6 +221,23 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
         a_addr[m] = hh * L::PLANE + ((br * 4 + (li >> 3)) * L::PITCH + bc * 8 + (li & 7)) * 16;
     }
 
+#ifdef SP3_TRACE
+    // instrumented build (tools/ab/trace_sp3.py): lane 0 of every wave of every 8th workgroup stamps the shader clock into LDS (a global store in
+    // the loop would make every wait drain it) and copies the stamps to a.ws at the end: [0] start, [1] prologue done, chunk c < 6 at 2 + 11 c:
+    // barrier reached, passed, taps 0..8 done; [120] loop done, [121] stores issued, [122] / [123] real time at the end / start, [124] HW id
+    const bool tracing = a.ws && (blockIdx.x % 8) == 0 && lane == 0;
+    unsigned long long* trl = reinterpret_cast<unsigned long long*>(sb + L::LDS_BYTES) + wave * 128;
+    unsigned long long* trc = reinterpret_cast<unsigned long long*>(a.ws) + ((blockIdx.x / 8) * 4 + wave) * 128;
+#define SP3_STAMP(slot) do { if (tracing) trl[slot] = __builtin_readcyclecounter(); } while (0)
+    if (tracing) {
+        for (int i = 0; i < 128; ++i) trl[i] = 0;
+        trl[123] = __builtin_amdgcn_s_memrealtime();
+        trl[124] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));
+    }
+    SP3_STAMP(0);
+#else
+#define SP3_STAMP(slot) do { } while (0)
+#endif
     f32x16 acc[4][NB];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -222,7 +255,13 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
     // trip is about one tap of a wave's MFMAs, and the wait counter is in order: a halo request (HBM latency) issued between two weight requests
     // is waited for with the second one, BD taps later
     auto chunk_body = [&](int c) {
+#ifdef SP3_TRACE
+        if (c < 6) SP3_STAMP(2 + 11 * c);
+#endif
         __syncthreads();                // stage c & 1 is complete; everybody has read all of the other stage
+#ifdef SP3_TRACE
+        if (c < 6) SP3_STAMP(3 + 11 * c);
+#endif
         const unsigned char* As = sb + (c & 1) * L::STAGE;
         u32x4 av[2][P];                 // the A operands of patch m are read while patch m - 1 is multiplied
         auto read_A = [&](int slot, int tap, int m) {
@@ -262,7 +301,8 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
 #if !(SP3_ABL & 16)
                 if (m == 0) {
 #pragma unroll
-                    for (int nn = 0; nn < NB; ++nn) Bhs[nn] = __builtin_bit_cast(f16x8, wq[set][nn][0]) * (_Float16)(1.f / RS);
+                    for (int nn = 0; nn < NB; ++nn)
+                        Bhs[nn] = (SP3_ABL & 128) ? __builtin_bit_cast(f16x8, wq[set][nn][0]) : __builtin_bit_cast(f16x8, wq[set][nn][0]) * (_Float16)(1.f / RS);
                 }
 #pragma unroll
                 for (int nn = 0; nn < NB; ++nn) {
@@ -280,9 +320,14 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
                 stage((c + 1) & 1, c + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef SP3_TRACE
+            if (c < 6) SP3_STAMP(4 + 11 * c + tap);
+#endif
         }
     };
+    SP3_STAMP(1);
     for (int c = 0; c < nchunks; ++c) chunk_body(c);
+    SP3_STAMP(120);
 
     // ---- epilogue: scale / shift (+ReLU), NHWC stores: accumulator register r of lane half hh is pixel (r >> 2, (r & 3) + 4 hh) of the patch ---
 #if !(SP3_ABL & 32)
@@ -290,6 +335,15 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
     const bool interior = oy0 + L::TH <= H && ox0 + L::TW <= W && (cb0 + NB) * 32 <= a.Cout;
     // fused GroupNorm statistics of the NEXT layer's normalisation (fcos.py:182-186): one {sum, sumsq} record per (spatial tile, pixel row of
     // waves), every group of it written by the wave that owns those couts (cmk_conv_gn_records: WROWS records per tile)
+    auto trace_out = [&]() {
+#ifdef SP3_TRACE
+        SP3_STAMP(121);
+        if (tracing) {
+            trl[122] = __builtin_amdgcn_s_memrealtime();
+            for (int i = 0; i < 128; ++i) trc[i] = trl[i];
+        }
+#endif
+    };
     const bool want_stats = a.gn_ws != nullptr;
     const float acc_scale = Pb.acc_scale * (1.f / SX);          // 1 / (S_x * S_w)
     auto put_stats = [&](int co, bool cvalid, float gs, float gss) {
@@ -339,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
             }
             if (want_stats) put_stats(co, true, gs2.x + gs2.y, gss2.x + gss2.y);
         }
+        trace_out();
         return;
     }
     // border tiles: the same walk; a store is predicated on its row (wave-uniform) and its column / cout (per lane, four compares per patch)
@@ -395,6 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
             if (want_stats) put_stats(co, cvalid, gs_b, gss_b);
         }
     }
+    trace_out();
 #endif
 }
 
@@ -403,9 +459,9 @@ static int launch_sp3_geo(ConvArgs& a, hipStream_t st) {
     typedef SP3L<GEO, P> L;
     static DeviceOnce once;
     int rc = once.run([]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp3_kernel<GEO, NB, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp3_kernel<GEO, NB, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_ALLOC);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp3_kernel<GEO, NB, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sp3_kernel<GEO, NB, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_ALLOC);
         return e == hipSuccess ? CMK_OK : fail(CMK_ELAUNCH, "conv_sp3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     });
     if (rc) return rc;
@@ -421,9 +477,9 @@ static int launch_sp3_geo(ConvArgs& a, hipStream_t st) {
     a.grid_y = cdiv(a.Cout, 32 * NB * SP3G<GEO>::WCOLS);
     const dim3 grid(((blocks + 7) / 8) * 8 * a.grid_y);
     if (a.p[0].in_scale)
-        hipLaunchKernelGGL((conv_sp3_kernel<GEO, NB, P, true>), grid, dim3(256), L::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((conv_sp3_kernel<GEO, NB, P, true>), grid, dim3(256), L::LDS_ALLOC, st, a);
     else
-        hipLaunchKernelGGL((conv_sp3_kernel<GEO, NB, P, false>), grid, dim3(256), L::LDS_BYTES, st, a);
+        hipLaunchKernelGGL((conv_sp3_kernel<GEO, NB, P, false>), grid, dim3(256), L::LDS_ALLOC, st, a);
     return check_launch("conv_sp3");
 }
 
