@@ -115,12 +115,15 @@ typedef struct {
      * input channels 16*chunk + 8*hh + 0..7 of output channel 32*tile + li (cout_pad = Cout rounded up to 128, zero filled).
      * No caller of this repository selects it by default (ops.ALLOW_SPLIT_BF16); NULL = not available. */
     const void* w_split;
-    /* OPT-IN, tune_wm 11 (conv_sp3.hip; tune_sc = 2 pieces, tune_wn = tile geometry 0..3): a 3x3 stride-1 conv as a DIRECT implicit GEMM on
+    /* OPT-IN, tune_wm 12 (tune_sc 32, tune_wn 4): the pointwise GEMM / gather form of tune_wm 10 on TWO fp16 pieces per operand, three products
+     * (half the MFMAs of the bf16 form, the same fp32-class error); takes pool_ws and res_mode 2 like tune_wm 10; packing w_splith (1 tap for a
+     * 1x1 conv, 9 tap-major for a 3x3 conv) and w_splith_scale as described next.
+     * OPT-IN, tune_wm 11 (conv_sp3.hip; tune_sc = 2 pieces, tune_wn = tile geometry 0..3): a 3x3 stride-1 conv as a DIRECT implicit GEMM on
      * v_mfma_f32_32x32x16_f16 with every fp32 operand split into TWO fp16 pieces (22 bits of significand: h = fp16(x), m = fp16(x - h), the
      * residual is exact) and the products m*h, h*m, h*h accumulated in fp32.  The representation error is below an fp32 GEMM's own accumulation
      * error, so the result carries the error of an fp32 accumulation — NOT the bits of the fp32-MFMA kernels.  Activations are split inside the
      * kernel (scaled by 2^-4, residual by 2^11: finite up to |x| = 1e6, 22 bits down to 2^-21); the caller packs the weights:
-     * w' = w * S_w, S_w the power of two with max |w'| in [2^14, 2^15); w_splith = 9 x cmk_splith_packed_halves(Cout, Cin) fp16 values,
+     * w' = w * S_w, S_w the power of two with max |w'| in [2^14, 2^15); w_splith = taps x cmk_splith_packed_halves(Cout, Cin) fp16 values,
      * [tap][Cin/16][cout_pad/32][piece h|m][lane 64][8] (lane = 32*hh + li: input channels 16*chunk + 8*hh + 0..7 of output channel 32*tile + li;
      * cout_pad = Cout rounded up to 128, zero filled); w_splith_scale = 1 / S_w.  Takes in_scale/in_shift, gn_ws (cmk_conv_gn_records(H, W,
      * 110 + geometry)), and in cmk_conv2d_nhwc_multi up to 10 problems that may differ in their weights.  No residual, split-K or pooled sums.
