@@ -392,3 +392,33 @@ def test_lazy_instances_between_the_plugins():
     b2.attach_roi(dict(det2), lambda d2: redo.append(1) or dict(d2, pred_masks=torch.zeros(n, k, 1, 28, 28)))
     i2 = [LazyInstances((8, 9), b2, i) for i in range(n)]
     assert len(i2[0]) == 4 and len(i2[1]) == 1 and FakeFcos.calls == 1 and redo == [1] and i2[1].has("pred_masks")
+
+
+def test_fp16_split_weight_packing_is_exact_to_22_bits():
+    """Host logic of the opt-in fp16-split forms (cmk.h w_splith): S_w is the power of two that puts max |w S_w| in [2^14, 2^15); h + m
+    reconstructs w S_w to 2^-22 relative for every weight within 2^17 of the layer's largest; the layout is [tap][chunk][tile][piece][lane][8]
+    with lane = 32 * hh + li holding input channels 16 chunk + 8 hh + e of output channel 32 tile + li; zero padding of Cin and Cout."""
+    import math
+    from centermask2_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for cout, cin, k in ((40, 48, 3), (130, 32, 1)):
+        w = torch.randn((cout, cin, k, k), generator=g) * 0.07
+        w[0, 0, 0, 0] = 0.9                                   # the layer's largest weight
+        w[1, 1, 0, 0] = 0.9 * 2.0 ** -16                      # near the bottom of the fully represented range
+        packed, inv_s = ops.pack_splith_weight(w)
+        s_w = 1.0 / inv_s
+        assert math.log2(s_w) == int(math.log2(s_w)) and 2.0 ** 14 <= 0.9 * s_w < 2.0 ** 15
+        taps, cin_pad, cout_pad = k * k, (cin + 15) // 16 * 16, (cout + 127) // 128 * 128
+        assert tuple(packed.shape) == (taps, cin_pad // 16, cout_pad // 32, 2, 64, 8) and packed.dtype == torch.float16
+        # undo the layout by the documented index formula
+        r = packed.reshape(taps, cin_pad // 16, cout_pad // 32, 2, 2, 32, 8)          # [tap][chunk][tile][piece][hh][li][e]
+        full = r.permute(3, 2, 5, 0, 1, 4, 6).reshape(2, cout_pad, taps, cin_pad)       # [piece][cout][tap][cin]
+        h, m = full[0].double(), full[1].double()
+        want = torch.zeros((cout_pad, taps, cin_pad), dtype=torch.float64)
+        want[:cout, :, :cin] = w.double().reshape(cout, cin, taps).permute(0, 2, 1) * s_w
+        err = (h + m - want).abs()
+        big = want.abs() >= 2.0 ** -2                          # both pieces normal fp16
+        assert float((err[big] / want.abs()[big]).max()) <= 2.0 ** -22
+        assert float(err[~big].max()) <= 2.0 ** -24 * 1.01     # below that: the absolute resolution of fp16's subnormals (2^-25 per piece)
+        assert float(h[cout:].abs().max()) == 0.0 and float(h[:, :, cin:].abs().max() if cin_pad > cin else 0.0) == 0.0
+        assert float((h - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -11      # h alone is fp16(w S_w)
