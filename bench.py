@@ -26,6 +26,7 @@ import torch.distributed as dist
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
+PEAK_16BIT_MATRIX_TFLOPS = 2010.0  # v_mfma_f32_32x32x16_{bf16,f16} measured on random operands (tools/probe/mfma_power_bf16.hip; nominal dense 2516 at 2.4 GHz): the pipe of the opt-in split kernels
 PROFILE_ROUND = "r03"            # prefix of the PMC summaries under profiles/ this bench quotes
 
 
@@ -335,10 +336,31 @@ def split_gemm_leg(body, dev, B, ref_out=None, steps=20, warmup=3, level=1):
             same_labels = bool(torch.equal(out["cls"], ref_out["cls"]))
             score_diff = float((out["score"] - ref_out["score"]).abs().max())
         moved = sum(1 for v in ops._TUNED.values() if v[0] in (10, 12))
+        # one instrumented eager step: what the split kernels reach on the 16-bit matrix pipe (products per fp32 product: 3 on fp16 pieces, 6 on bf16)
+        ops.PROFILE = []
+        with torch.no_grad():
+            model.inference_padded(x, sizes)
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for key, fl, by, e0, e1, shape, ex in prof:
+            a = agg.setdefault(key, dict(ms=0.0, flops=0.0, exec=0.0, launches=0))
+            a["ms"] += e0.elapsed_time(e1); a["flops"] += fl; a["exec"] += ex; a["launches"] += 1
+        kern = {}
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            products = 3 if (k.startswith("conv_sp3") or k.endswith(", 2>")) else 6 if (k.startswith("conv_pw") and k.endswith(", 1>")) else 0
+            if products:
+                t16 = products * a["exec"] / a["ms"] / 1e9
+                kern[k] = {"ms": round(a["ms"], 3), "launches": a["launches"], "alg_equiv_TFLOPs": round(a["flops"] / a["ms"] / 1e9, 1), "products_per_fp32_product": products,
+                           "mfma16_TFLOPs_executed": round(t16, 1), "frac_of_measured_16bit_peak": round(t16 / PEAK_16BIT_MATRIX_TFLOPS, 3)}
+        conv_ms = sum(a["ms"] for a in agg.values())
         res = {"images_per_sec": round(steps * B / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup, "body": body,
                "convs_moved": moved, "dtype": "f32 results; the moved convs multiply bf16 pieces (3 per fp32 operand, 6 products per fp32 product) and accumulate in f32",
                "same_detection_counts": same_counts, "same_labels_same_order": same_labels, "max_score_diff_vs_default": score_diff,
                "status": "opt-in (CMK_ALLOW_SPLIT_BF16=1 + a variant table naming tune 10/32/4); not used by `value`"}
+        res["split_kernels"] = kern
+        res["split_kernels_peak"] = "{} TFLOP/s: v_mfma_f32_32x32x16_bf16/f16 measured on random operands (tools/probe/mfma_power_bf16.hip); nominal dense 2516".format(PEAK_16BIT_MATRIX_TFLOPS)
+        res["all_convs_ms_instrumented"] = round(conv_ms, 3)
         if level >= 2:
             res["convs_3x3_moved"] = sum(1 for v in ops._TUNED.values() if v[0] == 11)
             res["dtype"] = ("f32 results; the convs named by the table (3x3 direct form, pointwise GEMMs) multiply 2 fp16 pieces per fp32 operand (22-bit operands, "

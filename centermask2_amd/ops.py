@@ -958,8 +958,11 @@ def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) 
         # (the shared-V form, sc 64, runs two such cout tiles per workgroup; a wave group without a tile issues no MFMAs: the same count)
         wgs = sum(cd(n, 2) for n, h, w in shapes) if wn == 2 else sum(n * cd(h, 12) * cd(w, 40) for n, h, w in shapes)
         return float(wgs * cd(cout, 32) * (cin_pad // 8) * 144 * 4096)
+    if wm == 11:     # direct 3x3 on split products (conv_sp3.hip), priced in fp32-equivalent FLOPs (x 3 products on the 16-bit pipe): tiles of geometry wn
+        th, tw, ct = ((8, 32, 128), (4, 32, 256), (16, 16, 128), (8, 16, 256))[wn]
+        return float(sum(n * cd(h, th) * cd(w, tw) for n, h, w in shapes) * th * tw) * (cd(cout, ct) * ct) * cin_pad * 9 * 2.0
     cout_pad = _lib.load().cmk_conv_cout_pad(cout)
-    if wm in (8, 9, 10):  # workgroup = 64*wn pixels x 128 couts; 9 = the gather form (K = 9 taps x Cin); 10 = the split form, priced in fp32-equivalent FLOPs
+    if wm in (8, 9, 10, 12):  # workgroup = 64*wn pixels x 128 couts; 9 = the gather form (K = 9 taps x Cin); 10 / 12 = the split forms, priced in fp32-equivalent FLOPs
         return float(sum(cd(n * h * w, 64 * wn) for n, h, w in shapes)) * (64 * wn) * (cd(cout, 128) * 128) * cin_pad * taps * 2.0
     if wm not in (1, 2):                      # cost-model / gather / split-K variants: geometry of the smallest tile
         wm, sc = 1, (32 if taps == 1 else 16)
