@@ -1,7 +1,7 @@
 """Same-session timing of conv_sp3 builds (ablations, variants): ab_sp3.py [--rounds R] <lib.so> [<lib.so> ...]
 One subprocess per (round, library), interleaved, best-of per shape.  Results of ablation builds are wrong by design; only times count."""
 import sys, os, subprocess
-SHAPES = [("OSA2_x", 200, 320, 128, 128, 0), ("OSA3_x", 100, 160, 160, 160, 1), ("fpn_p3", 100, 160, 256, 256, 1), ("fpn_p4", 50, 80, 256, 256, 3), ("roi", 14, 14, 256, 256, 2)]
+SHAPES = [("OSA2_x", 200, 320, 128, 128, 0), ("OSA3_x", 100, 160, 160, 160, 1), ("fpn_p3", 100, 160, 256, 256, 1), ("fpn_p4", 50, 80, 256, 256, 3), ("fpn_p5", 25, 40, 256, 256, 3), ("p6", 13, 20, 256, 256, 3), ("roi", 14, 14, 256, 256, 3)]
 if sys.argv[1] != "--one":
     args = sys.argv[1:]
     rounds, sc = 2, "64"
