@@ -187,7 +187,94 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvArgs a) {
         for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
-    if constexpr (SPLIT == 2) {
+    if constexpr (SPLIT == 2 && !GA) {
+        // 1x1 conv on two fp16 pieces, 32 channels per stage: a thread requests 16 bytes of a 128-byte line whose other seven sixteenths are requested by
+        // its neighbours in the same instruction (the 16-channel form takes half of every line now and the other half one chunk later: measured, the
+        // activation requests alone cost that form 44 % of its time, profiles/r03_conv_sp3.txt section 8), and a barrier spans 48 MFMAs of a wave
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr float SX = 0.0625f, RS = 2048.f;              // activation scale 2^-4, residual scale 2^11
+        constexpr int NIT = BM / 32;                            // 8 requests per thread and stage: row tid / 8 + 32 it, channels 4 (tid & 7) .. + 3 of the 32
+        constexpr int STAGE = (BM / 32) * 2 * 2 * 64 * 16;      // bytes per LDS stage: [row block][k16 half][piece][lane][8 fp16]
+        unsigned char* sb = reinterpret_cast<unsigned char*>(smem);
+        auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, f16x2{(_Float16)x, (_Float16)y}); };       // round to nearest even
+        auto unpk = [](unsigned p_) { const f16x2 h_ = __builtin_bit_cast(f16x2, p_); return f32x2{(float)h_.x, (float)h_.y}; };
+        const int oct = tid & 7;
+        int x_voff[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const long px = pix0 + it * 32 + (tid >> 3);
+            x_voff[it] = px < total_pix ? (int)((px * a.x_cs + a.x_co + oct * 4) * 4) : (int)0x80000000;
+        }
+        // row r = tid / 8 + 32 it is row (tid >> 3) of row block it; channels 4 oct .. : k16 half oct >> 2, lane half (oct & 3) >> 1, 8-byte half slot oct & 1
+        const int st_off = (((oct >> 2) * 2) * 64 + ((oct & 3) >> 1) * 32 + (tid >> 3)) * 16 + (oct & 1) * 8;
+        f32x4 xs[NIT];
+        auto load_X = [&](int c32) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) xs[it] = pw_buffer_load(rsrc, x_voff[it], c32 * 128, 0);
+        };
+        auto stage = [&](int buf) {
+            unsigned char* dst = sb + buf * STAGE + st_off;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const f32x4 x = xs[it] * SX;
+                u32x2 h, m_;
+                h.x = pk(x.x, x.y); h.y = pk(x.z, x.w);
+                const f32x2 h01 = unpk(h.x), h23 = unpk(h.y);
+                const f32x4 r1 = f32x4{x.x - h01.x, x.y - h01.y, x.z - h23.x, x.w - h23.y} * RS;      // exact: h holds the leading bits of x
+                m_.x = pk(r1.x, r1.y); m_.y = pk(r1.z, r1.w);
+                *reinterpret_cast<u32x2*>(dst + it * (4 * 64 * 16)) = h;
+                *reinterpret_cast<u32x2*>(dst + it * (4 * 64 * 16) + 64 * 16) = m_;
+            }
+        };
+        const u32x4* wsp = reinterpret_cast<const u32x4*>(a.w) + ((long)(co0 >> 5) * 2) * 64 + lane;      // wave-uniform base + lane
+        const long wstep = (long)(a.cout_pad >> 5) * 2 * 64;                                               // per 16 channels
+        u32x4 wb[2][2][2];                  // [k16 half][cout tile][piece]
+        auto load_Bs = [&](int s_, int k16) {
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int p_ = 0; p_ < 2; ++p_) wb[s_][nn][p_] = wsp[k16 * wstep + (nn * 2 + p_) * 64];
+        };
+        const int n32 = a.Cin >> 5;
+        load_X(0);
+        load_Bs(0, 0);
+        load_Bs(1, 1);
+        stage(0);
+        load_X(min(1, n32 - 1));
+        for (int c = 0; c < n32; ++c) {
+            __syncthreads();            // stage c & 1 is complete; everybody has read all of the other stage
+            const u32x4* ap = reinterpret_cast<const u32x4*>(sb + (c & 1) * STAGE) + (wm * MT * 4) * 64 + lane;
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                f16x8 Bhs[2];
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) Bhs[nn] = __builtin_bit_cast(f16x8, wb[s_][nn][0]) * (_Float16)(1.f / RS);      // meets the activations' scaled residual
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const u32x4 ah = ap[(m * 4 + s_ * 2 + 0) * 64], am = ap[(m * 4 + s_ * 2 + 1) * 64];
+                    if (s_ == 0 && m == 2) {        // the next stage's activations (in registers since the last stage) are split between the MFMA groups
+                        stage((c + 1) & 1);
+                        load_X(min(c + 2, n32 - 1));
+                    }
+                    const f16x8 Ah = __builtin_bit_cast(f16x8, ah), Am = __builtin_bit_cast(f16x8, am);
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) {
+                        f32x16 cacc = acc[m][nn];
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Am, Bhs[nn], cacc, 0, 0, 0);
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, wb[s_][nn][1]), cacc, 0, 0, 0);
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, wb[s_][nn][0]), cacc, 0, 0, 0);
+                        acc[m][nn] = cacc;
+                    }
+                }
+                load_Bs(s_, min(2 * (c + 1) + s_, 2 * n32 - 1));     // this half of the next stage's weights: in flight during the other half's MFMAs
+            }
+        }
+        __syncthreads();                // the epilogue may reuse the LDS
+    } else if constexpr (SPLIT == 2) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -601,7 +688,7 @@ static int launch_pw_mt(ConvArgs& a, hipStream_t st) {
     });
     if (rc0) return rc0;
 #else
-    constexpr int LDS_BYTES = SPLIT ? 2 * (BM / 32) * (SPLIT == 2 ? 2 : 3) * 64 * 16 : 2 * BM * PST * 4;       // 40 KB (MT 4) / 20 KB (MT 2) / 48 | 32 KB (split): under the 64 KB a kernel gets without an attribute
+    constexpr int LDS_BYTES = SPLIT == 2 && !GA ? 2 * (BM / 32) * 4 * 64 * 16 : SPLIT ? 2 * (BM / 32) * (SPLIT == 2 ? 2 : 3) * 64 * 16 : 2 * BM * PST * 4;       // 40 KB (MT 4) / 20 KB (MT 2) / 48 | 32 KB (split): under the 64 KB a kernel gets without an attribute
 #endif
     ConvProblem& p = a.p[0];
     p.tile_begin = 0;
