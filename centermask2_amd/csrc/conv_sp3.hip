@@ -4,9 +4,9 @@
 // TFLOP/s, for structural reasons.  The 16-bit instructions run at 2010.  Every fp32 operand is split into TWO fp16
 // pieces — x = h + m, h = fp16(x), m = fp16(x - h): 11 + 11 = 22 bits of significand, the residual x - h is exact in fp32 — and the three
 // products m*h, h*m, h*h are accumulated in fp32, small terms first (what is dropped, m*m, is 2^-22 of the product).  Measured: the
-// representation error is a third of an fp32 GEMM's own accumulation error (tools/split_bf16_numerics.py), i.e. the result carries the error
-// of an fp32 accumulation.  (Two BF16 pieces, 16 bits, were built first and measured 5x the fp32 path's end-to-end error: reg 1.4e-3 against
-// the 1e-3 bar; three bf16 pieces / six products are fp32-accurate but slower than Winograd on a 3x3 conv — profiles/r03_ablations.txt.)
+// representation error is a third of an fp32 GEMM's own accumulation error (profiles/r03_conv_sp3.txt section 3), i.e. the result carries the
+// error of an fp32 accumulation.  (Two BF16 pieces, 16 bits, were built first and measured 5x the fp32 path's end-to-end error: reg 1.4e-3 against
+// the 1e-3 bar; three bf16 pieces / six products are fp32-accurate but slower than Winograd on a 3x3 conv — same file.)
 // fp16's narrow exponent is handled by scaling, all powers of two (exact):
 //   activations  x' = x * 2^-4 (|x| up to 1e6 stays finite); the residual is stored as fp16((x' - h) * 2^11), so it keeps 11 bits down to
 //                |x| = 2^-21 (unscaled it would be subnormal below |x| = 0.06), and the weight piece it meets is multiplied by 2^-11 in
@@ -16,13 +16,13 @@
 //   the accumulator is multiplied by 2^4 / S_w in the epilogue (folded into the per-channel scale).
 // No transform, so no Winograd error amplification either.
 //
-// What the gather form of conv_pw.hip (tune_wm 10 on a 3x3 conv) pays nine times — the activation load, the split, the LDS write — is
+// What the gather form of conv_pw.hip (tune_wm 10 / 12 on a 3x3 conv) pays nine times — the activation load, the split, the LDS write — is
 // paid once here: a workgroup stages the HALO of its pixel tile, 16 input channels at a time, split into pieces, as
 //   LDS [stage 2][piece P][k half 2][halo row][pitch][8 fp16]
 // and the nine taps read the MFMA's A operand (32 pixels = a 4 x 8 patch, lane (li, hh) = pixel li, channels 8hh..8hh+7 of the chunk)
 // from it at a shifted address (an immediate offset of the ds_read).  The row pitch (40 | 24 sixteen-byte units) makes the four rows of a
-// patch tile the 512-byte bank space.  The weights come straight from L2/L1 into registers through a wave-uniform base, one tap ahead
-// (cmk_conv_desc.w_splith: [tap][Cin/16][cout_pad/32][piece 2][lane][8 fp16]).
+// patch tile the 512-byte bank space.  The weights come straight from L2/L1 into registers (buffer loads: lane offset + scalar offset), two taps
+// ahead on three register sets, one request per patch (cmk_conv_desc.w_splith: [tap][Cin/16][cout_pad/32][piece 2][lane][8 fp16]).
 //
 // Workgroup = 4 waves, wave tile = 4 patches (128 pixels) x NB cout tiles of 32, accumulators as in conv_pw (pixels on the rows, couts on the lanes):
 //   GEO 0: waves 2 (pixels) x 2 (couts);  tile  8 rows x 32 columns x 128 couts      the large maps of 128-cout layers (200 x 320)
@@ -485,8 +485,9 @@ static int launch_sp3_geo(ConvArgs& a, hipStream_t st) {
 
 // geo 0..3 (above), pieces = 2.  p[i].w = the fp16 split packing (tap-major), p[i].acc_scale = 1 / S_w, a.cout_pad = the packing's padded Cout (a multiple of 128).
 int launch_sp3(ConvArgs& a, int geo, int pieces, hipStream_t st) {
-    if ((a.Cin & 15) || a.cout_pad % 128 || a.cout_pad < a.Cout || a.ksplit > 1 || a.res_mode != 0 || a.in_relu)
-        return fail(CMK_EINVAL, "conv_sp3: needs Cin %% 16 == 0, no split-K / residual%s", "");
+    if ((a.Cin & 15) || a.cout_pad % 128 || a.cout_pad < a.Cout || a.ksplit > 1 || a.res_mode != 0 || a.in_relu ||
+        9L * (a.Cin >> 4) * (a.cout_pad >> 5) * 2 * 1024 >= (1L << 31))
+        return fail(CMK_EINVAL, "conv_sp3: needs Cin %% 16 == 0, no split-K / residual, split weights below 2 GiB%s", "");
     for (int i = 0; i < a.nprob; ++i) {
         const ConvProblem& p = a.p[i];
         if ((long)p.N * p.H * p.W * a.x_cs * 4 >= (1L << 31) || p.Ho != p.H || p.Wo != p.W || (!p.in_scale) != (!a.p[0].in_scale) || !p.w || !(p.acc_scale > 0.f))
