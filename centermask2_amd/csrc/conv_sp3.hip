@@ -25,7 +25,7 @@
 // ahead on three register sets, one request per patch (cmk_conv_desc.w_splith: [tap][Cin/16][cout_pad/32][piece 2][lane][8 fp16]).
 //
 // Workgroup = 4 waves, wave tile = 4 patches (128 pixels) x NB cout tiles of 32, accumulators as in conv_pw (pixels on the rows, couts on the lanes):
-//   GEO 0: waves 2 (pixels) x 2 (couts);  tile  8 rows x 32 columns x 128 couts      the large maps of 128-cout layers (200 x 320)
+//   GEO 0: waves 2 (pixels) x 2 (couts);  tile  8 rows x 32 columns x 128 couts      the large maps of 128-cout layers (200 x 320); NB = 1 (64 couts) for stem_2
 //   GEO 1: waves 1 x 4;                   tile  4 rows x 32 columns x 256 couts      100 x 160 maps of 256-cout layers (25 x 5 tiles, no waste)
 //   GEO 2: waves 2 x 2;                   tile 16 rows x 16 columns x 128 couts      RoI maps (14 x 14: one map per tile)
 //   GEO 3: waves 1 x 4;                   tile  8 rows x 16 columns x 256 couts      50 x 80 maps of 256-cout layers
@@ -495,7 +495,7 @@ int launch_sp3(ConvArgs& a, int geo, int pieces, hipStream_t st) {
     }
     if (pieces != 2) return fail(CMK_EINVAL, "conv_sp3: tune_sc = pieces per operand must be 2 (three pieces: tune_wm 10, the gather form of conv_pw)%s", "");
     switch (geo) {
-        case 0: return launch_sp3_geo<0, 2, 2>(a, st);
+        case 0: return a.Cout <= 64 ? launch_sp3_geo<0, 1, 2>(a, st) : launch_sp3_geo<0, 2, 2>(a, st);      // (64 couts: one cout tile per wave, no padded half)
         case 1: return launch_sp3_geo<1, 2, 2>(a, st);
         case 2: return launch_sp3_geo<2, 2, 2>(a, st);
         case 3: return launch_sp3_geo<3, 2, 2>(a, st);

@@ -758,7 +758,7 @@ def test_maxpool_with_folded_ese_gate(dev):
 
 SP3_CASES = [  # (n, h, w, cin, cout, geo, pieces): ragged maps, cout padding, every tile geometry; three pieces are refused
     (2, 37, 53, 64, 128, 0, 2), (1, 21, 70, 48, 80, 1, 2), (3, 14, 14, 256, 256, 2, 2), (2, 50, 80, 128, 256, 3, 2), (2, 13, 20, 32, 33, 0, 2),
-    (1, 9, 33, 272, 160, 3, 2), (2, 8, 32, 64, 128, 0, 3), (1, 19, 45, 96, 224, 1, 2)]
+    (1, 9, 33, 272, 160, 3, 2), (2, 8, 32, 64, 128, 0, 3), (1, 19, 45, 96, 224, 1, 2), (2, 21, 37, 32, 64, 0, 2), (1, 12, 40, 64, 48, 0, 2)]      # <= 64 couts: one cout tile per wave
 
 
 @pytest.mark.parametrize("case", SP3_CASES)
