@@ -976,7 +976,7 @@ def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) 
 _conv2d_plain = conv2d
 
 
-def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False) -> str:
+def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False, cout=None) -> str:
     """The template instantiation rocprofv3 will report (minus the `void cmk::` prefix and the argument list)."""
     if not tv or tuple(tv[:3]) == (0, 0, 0):
         return "conv_igemm_kernel<{}, {}, cost-model variant>".format(taps, stride)
@@ -991,7 +991,7 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False) -> str:
     if wm in (10, 12):
         return "conv_pw_kernel<4, {}, {}, {}, false, {}>".format("true" if pool else "false", "true" if taps == 9 else "false", "true" if upres else "false", 1 if wm == 10 else 2)
     if wm == 11:
-        return "conv_sp3_kernel<{}, 2, {}, {}>".format(wn, sc, "true" if aff else "false")
+        return "conv_sp3_kernel<{}, {}, {}, {}>".format(wn, 1 if (wn == 0 and cout is not None and cout <= 64) else 2, sc, "true" if aff else "false")
     if wm == 9:
         return "conv_pw_kernel<{}, false, true, false, {}, 0>".format(wn, sk)
     if wm == 7:
@@ -1011,7 +1011,7 @@ def conv2d(x, pc, y, **kw):  # noqa: F811
     descs = (ConvDesc * 1)()
     _fill_desc(descs[0], x, pc, y, kw.get("relu", False), kw.get("relu_upto"), kw.get("res"), kw.get("res_upsample", False), kw.get("in_relu", False))
     tv = _TUNED.get(_problem_key(descs, 1))
-    key = _kernel_name(taps, pc.stride, tv, pool=kw.get("pool") is not None and FUSE_POOL, upres=bool(kw.get("res_upsample")))
+    key = _kernel_name(taps, pc.stride, tv, pool=kw.get("pool") is not None and FUSE_POOL, upres=bool(kw.get("res_upsample")), cout=pc.cout)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _conv2d_plain(x, pc, y, **kw)
