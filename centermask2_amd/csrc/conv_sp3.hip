@@ -493,12 +493,17 @@ int launch_sp3(ConvArgs& a, int geo, int pieces, hipStream_t st) {
         if ((long)p.N * p.H * p.W * a.x_cs * 4 >= (1L << 31) || p.Ho != p.H || p.Wo != p.W || (!p.in_scale) != (!a.p[0].in_scale) || !p.w || !(p.acc_scale > 0.f))
             return fail(CMK_EINVAL, "conv_sp3: an input of 2 GiB or more, a strided conv, problems that differ in the input affine, or no split weights%s", "");
     }
-    if (pieces != 2) return fail(CMK_EINVAL, "conv_sp3: tune_sc = pieces per operand must be 2 (three pieces: tune_wm 10, the gather form of conv_pw)%s", "");
+    // tune_sc 2: two pieces per operand; 21: the same with ONE cout tile per wave (workgroups of 64 couts in geometries 0 / 2, of 128 in 1 / 3): less
+    // cout padding (three 64-cout workgroups cover 160 or 192 couts where two 128-cout ones pad them to 256), 3-4x the workgroups on the small maps, and
+    // 158 registers = three workgroups per CU; at the price of staging the halo once per 64 (128) couts.  Geometry 0 takes it by itself up to 64 couts.
+    if (pieces != 2 && pieces != 21)
+        return fail(CMK_EINVAL, "conv_sp3: tune_sc must be 2 (two pieces per operand) or 21 (the same, one cout tile per wave)%s", "");
+    const bool nb1 = pieces == 21 || (geo == 0 && a.Cout <= 64);
     switch (geo) {
-        case 0: return a.Cout <= 64 ? launch_sp3_geo<0, 1, 2>(a, st) : launch_sp3_geo<0, 2, 2>(a, st);      // (64 couts: one cout tile per wave, no padded half)
-        case 1: return launch_sp3_geo<1, 2, 2>(a, st);
-        case 2: return launch_sp3_geo<2, 2, 2>(a, st);
-        case 3: return launch_sp3_geo<3, 2, 2>(a, st);
+        case 0: return nb1 ? launch_sp3_geo<0, 1, 2>(a, st) : launch_sp3_geo<0, 2, 2>(a, st);
+        case 1: return nb1 ? launch_sp3_geo<1, 1, 2>(a, st) : launch_sp3_geo<1, 2, 2>(a, st);
+        case 2: return nb1 ? launch_sp3_geo<2, 1, 2>(a, st) : launch_sp3_geo<2, 2, 2>(a, st);
+        case 3: return nb1 ? launch_sp3_geo<3, 1, 2>(a, st) : launch_sp3_geo<3, 2, 2>(a, st);
     }
     return fail(CMK_EINVAL, "conv_sp3: geometry 0..3%s", "");
 }

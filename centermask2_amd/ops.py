@@ -317,7 +317,7 @@ def _variant_on_menu(tv) -> bool:
     if wm == 12:                      # pointwise GEMM from fp16-split products (two pieces, three products)
         return ALLOW_SPLIT_F16 and sc == 32 and wn == 4 and sk == 1
     if wm == 11:                      # direct 3x3 conv from bf16-split products (conv_sp3.hip): sc = pieces, wn = geometry
-        return ALLOW_SPLIT_F16 and sc == 2 and 0 <= wn <= 3 and sk == 1
+        return ALLOW_SPLIT_F16 and sc in (2, 21) and 0 <= wn <= 3 and sk == 1
     return (wm in (1, 2, 5, 6, 7, 8, 9) and sc in (16, 32) and 1 <= wn <= 7 and sk in (1, 2, 4, 8)) or tuple(tv[:3]) == (0, 0, 0)
 
 
@@ -381,6 +381,7 @@ def _tune(descs, n, key) -> None:
         if ALLOW_SPLIT_F16:
             cands += [(12, 32, 4, 1)]                               # ... and the fp16 two-piece form of the gather GEMM
             cands += [(11, 2, g, 1) for g in range(4)]              # opt-in: direct 3x3 on two fp16 pieces per operand (conv_sp3.hip), four tile geometries
+            cands += [(11, 21, g, 1) for g in range(4)]             # ... one cout tile per wave: less cout padding, more and smaller workgroups
     if d0.ksize == 1:
         cands += [(8, 32, mt, sk) for mt in (4, 2) for sk in sks]   # pointwise GEMM kernel (conv_pw.hip), 256- or 128-pixel workgroups; same K order, same bits
         if ALLOW_SPLIT_BF16:
@@ -960,6 +961,8 @@ def executed_flops(taps: int, stride: int, tv, shapes, cin_pad: int, cout: int) 
         return float(wgs * cd(cout, 32) * (cin_pad // 8) * 144 * 4096)
     if wm == 11:     # direct 3x3 on split products (conv_sp3.hip), priced in fp32-equivalent FLOPs (x 3 products on the 16-bit pipe): tiles of geometry wn
         th, tw, ct = ((8, 32, 128), (4, 32, 256), (16, 16, 128), (8, 16, 256))[wn]
+        if sc == 21 or (wn == 0 and cout <= 64):
+            ct //= 2
         return float(sum(n * cd(h, th) * cd(w, tw) for n, h, w in shapes) * th * tw) * (cd(cout, ct) * ct) * cin_pad * 9 * 2.0
     cout_pad = _lib.load().cmk_conv_cout_pad(cout)
     if wm in (8, 9, 10, 12):  # workgroup = 64*wn pixels x 128 couts; 9 = the gather form (K = 9 taps x Cin); 10 / 12 = the split forms, priced in fp32-equivalent FLOPs
@@ -991,7 +994,7 @@ def _kernel_name(taps, stride, tv, aff=False, pool=False, upres=False, cout=None
     if wm in (10, 12):
         return "conv_pw_kernel<4, {}, {}, {}, false, {}>".format("true" if pool else "false", "true" if taps == 9 else "false", "true" if upres else "false", 1 if wm == 10 else 2)
     if wm == 11:
-        return "conv_sp3_kernel<{}, {}, {}, {}>".format(wn, 1 if (wn == 0 and cout is not None and cout <= 64) else 2, sc, "true" if aff else "false")
+        return "conv_sp3_kernel<{}, {}, 2, {}>".format(wn, 1 if (sc == 21 or (wn == 0 and cout is not None and cout <= 64)) else 2, "true" if aff else "false")
     if wm == 9:
         return "conv_pw_kernel<{}, false, true, false, {}, 0>".format(wn, sk)
     if wm == 7:

@@ -115,7 +115,9 @@ typedef struct {
      * input channels 16*chunk + 8*hh + 0..7 of output channel 32*tile + li (cout_pad = Cout rounded up to 128, zero filled).
      * No caller of this repository selects it by default (ops.ALLOW_SPLIT_BF16); NULL = not available. */
     const void* w_split;
-    /* OPT-IN, tune_wm 12 (tune_sc 32, tune_wn 4): the pointwise GEMM / gather form of tune_wm 10 on TWO fp16 pieces per operand, three products
+    /* (tune_wm 11 also takes tune_sc 21: the same geometries with one cout tile per wave — workgroups of 64 / 128 couts: less cout padding for
+     * layers of 160 / 192 couts, more and smaller workgroups for the small maps.)
+     * OPT-IN, tune_wm 12 (tune_sc 32, tune_wn 4): the pointwise GEMM / gather form of tune_wm 10 on TWO fp16 pieces per operand, three products
      * (half the MFMAs of the bf16 form, the same fp32-class error); takes pool_ws and res_mode 2 like tune_wm 10; packing w_splith (1 tap for a
      * 1x1 conv, 9 tap-major for a 3x3 conv) and w_splith_scale as described next.
      * OPT-IN, tune_wm 11 (conv_sp3.hip; tune_sc = 2 pieces, tune_wn = tile geometry 0..3): a 3x3 stride-1 conv as a DIRECT implicit GEMM on

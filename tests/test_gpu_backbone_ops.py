@@ -758,7 +758,8 @@ def test_maxpool_with_folded_ese_gate(dev):
 
 SP3_CASES = [  # (n, h, w, cin, cout, geo, pieces): ragged maps, cout padding, every tile geometry; three pieces are refused
     (2, 37, 53, 64, 128, 0, 2), (1, 21, 70, 48, 80, 1, 2), (3, 14, 14, 256, 256, 2, 2), (2, 50, 80, 128, 256, 3, 2), (2, 13, 20, 32, 33, 0, 2),
-    (1, 9, 33, 272, 160, 3, 2), (2, 8, 32, 64, 128, 0, 3), (1, 19, 45, 96, 224, 1, 2), (2, 21, 37, 32, 64, 0, 2), (1, 12, 40, 64, 48, 0, 2)]      # <= 64 couts: one cout tile per wave
+    (1, 9, 33, 272, 160, 3, 2), (2, 8, 32, 64, 128, 0, 3), (1, 19, 45, 96, 224, 1, 2), (2, 21, 37, 32, 64, 0, 2), (1, 12, 40, 64, 48, 0, 2),      # <= 64 couts: one cout tile per wave
+    (1, 19, 45, 96, 160, 0, 21), (2, 9, 33, 48, 192, 1, 21), (2, 14, 14, 64, 256, 2, 21), (1, 25, 40, 224, 224, 3, 21), (1, 9, 9, 32, 64, 0, 3)]     # one cout tile per wave on request (tune_sc 21); other values refused
 
 
 @pytest.mark.parametrize("case", SP3_CASES)
@@ -791,7 +792,7 @@ def test_conv_direct_split_f16_form(dev, case, monkeypatch):
     ops._fill_desc(d[0], xv, pc, y, False, relu_upto, None, False, False)
     d[0].tune_wm, d[0].tune_sc, d[0].tune_wn = 11, pieces, geo
     lib = _lib.load()
-    if pieces != 2:
+    if pieces not in (2, 21):
         assert lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()) != 0
         return
     _lib.check(lib.cmk_conv2d_nhwc(ctypes.byref(d[0]), ops._stream()), "conv_sp3")

@@ -19,7 +19,7 @@ for k, v in list(ops._TUNED.items()):            # every conv the pointwise GEMM
         ops._TUNED[k] = (12, 32, 4); moved += 1
 incumbent = {k: v for k, v in ops._TUNED.items() if k[0] == 3 and k[1] == 1}
 for k in incumbent: del ops._TUNED[k]
-ops.TUNE_ONLY = lambda key: [incumbent[key]] + [(11, 2, g) for g in range(4)] if key in incumbent else [(0, 0, 0)]
+ops.TUNE_ONLY = lambda key: [incumbent[key]] + [(11, 2, g) for g in range(4)] + [(11, 21, g) for g in range(4)] if key in incumbent else [(0, 0, 0)]
 ops.TUNE_REPS, ops.TUNE_ROUNDS = 4, 3
 ops.PAIR_TOWERS = False                          # the tower launches are tuned as single-tower launches (the pair takes that entry)
 ops.set_autotune(True)
@@ -38,6 +38,6 @@ for key, times in ops.TUNE_LOG:
     keep = best if (best[0] != 11 or times[best] * margin < t_inc) else inc
     ops._TUNED[key] = keep[:3] if keep[3] == 1 else keep
     won += keep[0] == 11
-    print("%-90s inc %s %.3f | %s | -> %s" % (ops._key_to_str(key), incumbent[key], t_inc, " ".join("g%d %.3f" % (tv[2], ms) for tv, ms in times.items() if tv[0] == 11), ops._TUNED[key]), flush=True)
+    print("%-90s inc %s %.3f | %s | -> %s" % (ops._key_to_str(key), incumbent[key], t_inc, " ".join("g%d%s %.3f" % (tv[2], "n" if tv[1] == 21 else "", ms) for tv, ms in times.items() if tv[0] == 11), ops._TUNED[key]), flush=True)
 ops.save_tuned(out)
 print("3x3 problems: %d, moved to the direct split form: %d; pointwise convs on the fp16 two-piece form: %d; table: %s" % (len(incumbent), won, moved, out))
