@@ -124,13 +124,20 @@ def roofline_leg(model, x, sizes):
         a["bytes"] += by
         a["exec"] += ex
         a["launches"] += 1
+    def pipe(k):      # (MFMA products per fp32 product, peak of that pipe): the opt-in split kernels run on the 16-bit matrix instructions
+        if k.startswith("conv_sp3") or (k.startswith("conv_pw") and k.endswith(", 2>")):
+            return 3, PEAK_16BIT_MATRIX_TFLOPS
+        if k.startswith("conv_pw") and k.endswith(", 1>"):
+            return 6, PEAK_16BIT_MATRIX_TFLOPS
+        return 1, PEAK_F32_MATRIX_TFLOPS
     dom = max(agg, key=lambda k: agg[k]["ms"])
     d = agg[dom]
+    dprod, dpeak = pipe(dom)
     total_ms = sum(a["ms"] for a in agg.values())
     khash = ops.kernel_source_hash()
     roof = {
-        "bound": "mfma", "kernel": dom, "achieved": round(d["exec"] / d["ms"] / 1e9, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(d["exec"] / d["ms"] / 1e9 / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None, "mfma_busy": None,
+        "bound": "mfma", "kernel": dom, "achieved": round(dprod * d["exec"] / d["ms"] / 1e9, 2), "peak": dpeak,
+        "unit": "TFLOP/s", "frac": round(dprod * d["exec"] / d["ms"] / 1e9 / dpeak, 4), "traffic": None, "mfma_busy": None,
         "definition": "achieved = executed MFMA FLOPs (Winograd-domain, tile padding included) / HIP-event time of the kernel's launches",
         "alg_equiv_TFLOPs": round(d["flops"] / d["ms"] / 1e9, 2),
         "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
@@ -141,7 +148,7 @@ def roofline_leg(model, x, sizes):
                       "alg_equiv_TFLOPs": round(sum(a["flops"] for a in agg.values()) / total_ms / 1e9, 2),
                       "frac": round(sum(a["exec"] for a in agg.values()) / total_ms / 1e9 / PEAK_F32_MATRIX_TFLOPS, 4),
                       "alg_GBps": round(sum(a["bytes"] for a in agg.values()) / total_ms / 1e6, 1)},
-        "per_kernel": {k: {"ms": round(a["ms"], 3), "exec_TFLOP/s": round(a["exec"] / a["ms"] / 1e9, 1), "frac": round(a["exec"] / a["ms"] / 1e9 / PEAK_F32_MATRIX_TFLOPS, 3),
+        "per_kernel": {k: {"ms": round(a["ms"], 3), "exec_TFLOP/s": round(pipe(k)[0] * a["exec"] / a["ms"] / 1e9, 1), "frac": round(pipe(k)[0] * a["exec"] / a["ms"] / 1e9 / pipe(k)[1], 3),
                            "alg_equiv_TFLOPs": round(a["flops"] / a["ms"] / 1e9, 1), "launches": a["launches"]}
                        for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
     }
@@ -387,6 +394,9 @@ def main():
     ap.add_argument("--no-autotune", action="store_true", help="use the library's cost model instead of the measured conv tile-variant table")
     ap.add_argument("--tune-file", default=None, help="conv variant table (default: centermask2_amd/tuned/mi355x_<body>_b<B>_800x1280.json)")
     ap.add_argument("--save-tuned", action="store_true", help="write the variant table after start-up tuning")
+    ap.add_argument("--path", choices=("fp32", "split"), default="fp32",
+                    help="fp32 (default): every conv on the fp32 matrix instruction.  split: the OPT-IN kernels — fp32 results from two fp16 pieces per operand on the "
+                         "16-bit matrix instructions, table tuned/*_split3.json (DESIGN section 3 'Split products'); `dtype` and `config.path` of the line say so")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -410,6 +420,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from centermask2_amd import synthetic as S
+    from centermask2_amd import ops
+    if args.path == "split":                       # before build(): the split weight copies are packed with the model
+        ops.ALLOW_SPLIT_BF16 = ops.ALLOW_SPLIT_F16 = True
     model, sd = build(args.body, dev)
     B = args.batch
     x = S.make_synthetic_images(B, 800, 1280, seed0=1234, first=rank * B).to(dev)   # resident in HBM before timing
@@ -426,7 +439,7 @@ def main():
     use_graph = not args.no_graph
     graph = None
     from centermask2_amd import ops
-    tune_file = args.tune_file or os.path.join(ROOT, "centermask2_amd", "tuned", "mi355x_{}_b{}_800x1280.json".format(args.body, B))
+    tune_file = args.tune_file or os.path.join(ROOT, "centermask2_amd", "tuned", "mi355x_{}_b{}_800x1280{}.json".format(args.body, B, "_split3" if args.path == "split" else ""))
     n_loaded = ops.load_tuned(tune_file) if (os.path.exists(tune_file) and not args.no_autotune) else 0
     with torch.no_grad():
         ops.set_autotune(not args.no_autotune)   # first call: packs weights, sets kernel attributes; conv problems missing from the
@@ -552,10 +565,11 @@ def main():
                 "metric": "images/sec whole-node (V2-39-eSE 3x800x1280)" if args.body == "V-39-eSE" else "images/sec whole-node ({} 3x800x1280)".format(args.body),
                 "value": round(total_images / elapsed, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "dtype": "f32" if args.path == "fp32" else "f32 results from 2 fp16 pieces per fp32 operand (22-bit operands, 3 products per fp32 product, f32 accumulation) on the convs the table names",
+                "data": "synthetic",
                 "config": {"workload": "Full CenterMask2 {} (VoVNetV2-FPN + FCOS + CenterROIHeads/SAG-Mask/MaskIoU + ROIAlignV2), bs={} per GPU, "
                                        "3x800x1280, end-to-end (BASELINE configs[3])".format(args.body, B),
-                           "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp{}".format(world),
+                           "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp{}".format(world), "path": args.path,
                            "launch": "hip-graph" if graph is not None else "eager",
                            "conv_variants": "measured table: {} problems loaded from {}, {} timed at start-up".format(
                                n_loaded, os.path.relpath(tune_file, ROOT), n_tuned - n_loaded) if not args.no_autotune else "library cost model",
@@ -568,9 +582,9 @@ def main():
                 result["sustained"] = sustained
                 result["fed"] = fed
                 result["plugin_api"] = plugin_api
-            if args.body == "V-39-eSE" and world == 1 and not args.no_extras:
+            if args.body == "V-39-eSE" and world == 1 and not args.no_extras and args.path == "fp32":
                 result["v99"] = other_body_leg("V-99-eSE", dev, B)
-            if world == 1 and not args.no_extras:
+            if world == 1 and not args.no_extras and args.path == "fp32":      # (--path split IS the opt-in path: nothing to report beside it)
                 result["split_gemm"] = split_gemm_leg(args.body, dev, B, out)
                 result["split_direct3x3"] = split_gemm_leg(args.body, dev, B, out, level=2)
                 if args.body == "V-39-eSE":
