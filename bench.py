@@ -249,7 +249,7 @@ def cpu_baseline_leg(sd, conv_body, budget_s=25.0):
             "sample": "{} image(s) 3x800x1280 (batch 1, full model incl. NMS/ROI heads) after 1 warm-up, torch {} CPU fp32".format(n, torch.__version__)}, results
 
 
-def other_body_leg(body, dev, B, steps=5, warmup=2):
+def other_body_leg(body, dev, B, steps=5, warmup=2, keep=None):
     """BASELINE config 5's per-GPU workload (the V-99-eSE body, 8 x 3x800x1280) through the same graph-replay step, a bounded number of
     steps — an extra key of the default run, so that the driver's bench record carries it; never `value`."""
     from centermask2_amd import ops, synthetic as S
@@ -282,6 +282,8 @@ def other_body_leg(body, dev, B, steps=5, warmup=2):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         assert not bool(out["overflow"].any())
+        if keep is not None:                        # the detections of this body on the fp32 path: what its opt-in legs are compared with
+            keep.update({k: out[k].clone() for k in ("counts", "cls", "score")})
         return {"images_per_sec": round(steps * B / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
                 "workload": "Full CenterMask2 {} , bs={}, 3x800x1280, hip-graph (BASELINE configs[4] per-GPU share)".format(body, B),
                 "conv_variants_loaded": n_loaded, "detections_per_image": out["counts"].cpu().tolist()}
@@ -583,13 +585,14 @@ def main():
                 result["fed"] = fed
                 result["plugin_api"] = plugin_api
             if args.body == "V-39-eSE" and world == 1 and not args.no_extras and args.path == "fp32":
-                result["v99"] = other_body_leg("V-99-eSE", dev, B)
+                v99_out = {}
+                result["v99"] = other_body_leg("V-99-eSE", dev, B, keep=v99_out)
             if world == 1 and not args.no_extras and args.path == "fp32":      # (--path split IS the opt-in path: nothing to report beside it)
                 result["split_gemm"] = split_gemm_leg(args.body, dev, B, out)
                 result["split_direct3x3"] = split_gemm_leg(args.body, dev, B, out, level=2)
                 if args.body == "V-39-eSE":
-                    result["split_gemm_v99"] = split_gemm_leg("V-99-eSE", dev, B, None, steps=5, warmup=2)
-                    result["split_direct3x3_v99"] = split_gemm_leg("V-99-eSE", dev, B, None, steps=5, warmup=2, level=2)
+                    result["split_gemm_v99"] = split_gemm_leg("V-99-eSE", dev, B, v99_out or None, steps=5, warmup=2)
+                    result["split_direct3x3_v99"] = split_gemm_leg("V-99-eSE", dev, B, v99_out or None, steps=5, warmup=2, level=2)
             if cpu is not None:
                 result["cpu_baseline"] = cpu
                 result["ap_delta"] = ap
