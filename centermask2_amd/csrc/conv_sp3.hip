@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv_sp3_kernel(const ConvArgs a) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     constexpr int WROWS = 4 / G::WCOLS;
     constexpr int IT = L::IT;
+    static_assert((IT - 1) * 256 < L::ITEMS && IT <= 8, "only a thread's last staging item may fall outside the halo; the requests are spread over 8 slots");
     extern __shared__ __attribute__((aligned(16))) unsigned char sb[];
 
     const int tid = threadIdx.x;
